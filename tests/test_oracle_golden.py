@@ -1,0 +1,111 @@
+"""CPU: the oracle restatement reproduces the golden vectors produced by the reference's
+own modules (tests/golden/*.npz, generator oracle/gen_golden.py).  Tolerances are fp32
+re-association noise (the oracle uses explicit matmul/softmax, the reference nn.MultiheadAttention)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import demo_oracle as O
+
+TOL = dict(rtol=2e-4, atol=2e-5)
+
+
+def _prefixed(sd, prefix):
+    return {prefix + k: v for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("name,C,H", [("fusion_c128_h4", 128, 4), ("fusion_c64_h2", 64, 2)])
+def test_fusion_eval(golden, name, C, H):
+    g = golden(name)
+    sd = _prefixed(g["sd"], "generalFusion.")
+    spec = O.Spec(feat_dim=C, moe_head=H)
+    for B in (1, 2, 4):
+        e = g[f"eval_b{B}"]
+        caches, globs = [e[f"in{i}"] for i in range(3)], [e[f"in{i}"] for i in range(3, 6)]
+        feats = O.hdm(sd, "generalFusion.", caches, globs, spec)
+        for i, f in enumerate(feats):
+            torch.testing.assert_close(f, e[f"hdm{i}"], **TOL)
+        gate = O.atmoe_gate(sd, "generalFusion.moe.", feats, spec, training=False)
+        torch.testing.assert_close(gate, e["gate"].reshape(B, H, 7), **TOL)
+        out = O.general_fusion(sd, caches, globs, spec, training=False)
+        torch.testing.assert_close(out, e["out"].reshape(B, 7 * C), **TOL)
+    spec.atm = False
+    out = O.general_fusion(sd, caches, globs, spec, training=False)
+    torch.testing.assert_close(out, g["eval_b4"]["out_hdm_only"], **TOL)
+
+
+@pytest.mark.parametrize("name,C,H", [("fusion_c128_h4", 128, 4), ("fusion_c64_h2", 64, 2)])
+def test_fusion_train_and_grads(golden, name, C, H):
+    g = golden(name)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k)
+          for k, v in _prefixed(g["sd"], "generalFusion.").items()}
+    spec = O.Spec(feat_dim=C, moe_head=H)
+    t = g["train_b4"]
+    ins = [t[f"in{i}"].clone().requires_grad_(True) for i in range(6)]
+    upd = {}
+    out = O.general_fusion(sd, ins[:3], ins[3:], spec, training=True, updates=upd)
+    torch.testing.assert_close(out, t["out"], **TOL)
+    assert float(t["loss"]) == 0.0
+    (out * t["w"]).sum().backward()
+    for i in range(6):
+        torch.testing.assert_close(ins[i].grad, t[f"gin{i}"], rtol=1e-3, atol=1e-5)
+    for k, v in g["sd_after_train"].items():
+        torch.testing.assert_close(upd["generalFusion." + k].to(v.dtype), v, **TOL)
+    if "grads" in g:
+        for k, v in g["grads"].items():
+            torch.testing.assert_close(sd["generalFusion." + k].grad, v, rtol=1e-3, atol=1e-5)
+
+
+def test_clip_visual(golden):
+    g = golden("clip_w128_l2")
+    spec = O.Spec(arch="clip", img_h=64, img_w=32, width=128, layers=2, heads=2, feat_dim=64)
+    out = O.clip_visual(g["sd"], "", g["img"], g["cv"], spec)
+    torch.testing.assert_close(out, g["out"], **TOL)
+    out = O.clip_visual(g["sd"], "", g["img"], None, spec)
+    torch.testing.assert_close(out, g["out_nocv"], **TOL)
+
+
+def test_vit_visual(golden):
+    g = golden("vit_w128_l2")
+    spec = O.Spec(arch="vit", img_h=64, img_w=32, width=128, layers=2, heads=2, feat_dim=128, camera_num=3, sie_coe=1.5)
+    out = O.vit_visual(g["sd"], "", g["img"], g["cam"], spec)
+    torch.testing.assert_close(out, g["out"], **TOL)
+
+
+def test_pife(golden):
+    g = golden("pife_c64")
+    sd = _prefixed(g["sd"], "rgb_reduce.")
+    out = O.pife_reduce(sd, "rgb_reduce", g["cls"], g["patches"], O.Spec(feat_dim=64))
+    torch.testing.assert_close(out, g["out"], **TOL)
+
+
+def test_losses(golden):
+    g = golden("losses")
+    torch.testing.assert_close(O.xent_label_smooth(g["score"], g["target"]), g["xent"], **TOL)
+    torch.testing.assert_close(O.triplet_soft_margin(g["feat"], g["target"]), g["triplet"], **TOL)
+
+
+def test_eval_func(golden):
+    g = golden("evalfunc")
+    cmc, mAP = O.r1_map(g["feats"], g["pids"].numpy(), g["camids"].numpy(), int(g["nq"]))
+    np.testing.assert_allclose(cmc, g["cmc"].numpy(), rtol=1e-6)
+    assert abs(mAP - float(g["mAP"])) < 1e-6
+
+
+def test_model_forward_shapes():
+    spec = O.Spec(arch="clip", img_h=64, img_w=32, width=128, layers=2, heads=2, feat_dim=64, moe_head=2,
+                  num_classes=11, camera_num=3)
+    sd = O.init_state_dict(spec, seed=1)
+    x = {k: torch.randn(4, 3, 64, 32) for k in ("RGB", "NI", "TI")}
+    cam = torch.tensor([0, 1, 2, 0])
+    assert O.model_forward(sd, spec, x, cam, return_pattern=1).shape == (4, 3 * 64)
+    assert O.model_forward(sd, spec, x, cam, return_pattern=2).shape == (4, 7 * 64)
+    assert O.model_forward(sd, spec, x, cam, return_pattern=3).shape == (4, 10 * 64)
+    out = O.model_forward(sd, spec, x, cam, training=True, updates={})
+    assert [tuple(o.shape) for o in out[:4]] == [(4, 11), (4, 448), (4, 11), (4, 192)] and out[4] == 0
+    spec.direct = 0
+    sd = O.init_state_dict(spec, seed=1)
+    out = O.model_forward(sd, spec, x, cam, training=True, updates={})
+    assert len(out) == 9
+    loss = O.train_loss(out, torch.tensor([0, 0, 1, 1]))
+    assert torch.isfinite(loss)
