@@ -1,0 +1,99 @@
+"""ctypes binding of libdemo_hip.so (the C ABI declared in include/demo_hip.h).
+
+There is deliberately no fallback: if the shared library is missing or a symbol cannot be
+resolved, importing/using the product path raises.  Build it with
+`make -C demo2_amd/csrc` (or `python -c "import __graft_entry__ as g; g.build()"`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdemo_hip.so")
+HEADER_PATH = os.path.join(_HERE, "..", "include", "demo_hip.h")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_QUICKGELU, ACT_GELU = 0, 1, 2
+
+
+class DemoHipError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("a_rs", C.c_int64), ("a_cs", C.c_int64), ("b_rs", C.c_int64), ("b_cs", C.c_int64), ("c_rs", C.c_int64),
+        ("dtA", C.c_int32), ("dtB", C.c_int32), ("dtC", C.c_int32),
+        ("act", C.c_int32), ("alpha", C.c_float),
+        ("batch1", C.c_int32), ("batch2", C.c_int32),
+        ("sA1", C.c_int64), ("sA2", C.c_int64), ("sB1", C.c_int64), ("sB2", C.c_int64),
+        ("sC1", C.c_int64), ("sC2", C.c_int64), ("sBias1", C.c_int64), ("sBias2", C.c_int64),
+        ("act_grad_pre", C.c_void_p), ("dtPre", C.c_int32), ("act_grad_kind", C.c_int32), ("accumulate", C.c_int32),
+        ("pre_out", C.c_void_p),
+    ]
+
+
+_P, _I, _L, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
+
+# name -> argtypes (restype is int for all but demo_last_error); mirrors include/demo_hip.h
+PROTOTYPES = {
+    "demo_abi_version": [],
+    "demo_gemm": [C.POINTER(GemmDesc), _P],
+    "demo_gemm_desc_size": [],
+    "demo_cast_f32_bf16": [_P, _P, _L, _P],
+    "demo_cast_bf16_f32": [_P, _P, _L, _P],
+    "demo_transpose": [_P, _P, _I, _I, _I, _P],
+    "demo_colsum": [_P, _P, _I, _I, _L, _I, _I, _P],
+    "demo_im2col": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "demo_embed_tokens": [_P, _I, _P, _P, _P, _P, _F, _I, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P],
+    "demo_layernorm_fwd": [_P, _P, _P, _F, _P, _I, _P, _P, _I, _I, _P],
+    "demo_layernorm_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P],
+    "demo_batchnorm_fwd": [_P, _P, _P, _P, _P, _I, _F, _F, _P, _I, _P, _P, _I, _I, _I, _I, _I, _L, _L, _P, _P],
+    "demo_attention_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "demo_pife_pool_cat": [_P, _I, _P, _I, _I, _I, _P],
+    "demo_set_token0": [_P, _I, _P, _L, _I, _I, _I, _P],
+    "demo_get_token0": [_P, _I, _P, _L, _I, _I, _I, _P],
+    "demo_hdm_softmax_pool": [_P, _L, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F, _U64, _P],
+    "demo_hdm_vbias": [_P, _P, _L, _P, _I, _I, _I, _P],
+    "demo_atmoe_gate_softmax": [_P, _P, _P, _I, _I, _I, _P],
+}
+
+_lib = None
+
+
+def header_symbols():
+    """Every function name declared in include/demo_hip.h (used by the CPU export test)."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(demo_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises DemoHipError when the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DemoHipError(f"{LIB_PATH} not found: build the HIP extension first (make -C demo2_amd/csrc). "
+                           "There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing -> loud
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.demo_last_error.argtypes = []
+    lib.demo_last_error.restype = C.c_char_p
+    if lib.demo_gemm_desc_size() != C.sizeof(GemmDesc):
+        raise DemoHipError("demo_gemm_desc layout mismatch between include/demo_hip.h and demo2_amd/_lib.py")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().demo_last_error()
+        raise DemoHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

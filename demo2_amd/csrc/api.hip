@@ -1,0 +1,26 @@
+// C-ABI plumbing: error text, version, and the demo_gemm dispatcher.
+#include "common.h"
+
+thread_local char g_demo_err[512] = {0};
+
+int demo_gemm_generic(const demo_gemm_desc& d, hipStream_t s);
+int demo_gemm_bf16_eligible(const demo_gemm_desc& d);
+int demo_gemm_bf16(const demo_gemm_desc& d, hipStream_t s);
+
+extern "C" int demo_abi_version(void) { return 1; }
+extern "C" const char* demo_last_error(void) { return g_demo_err; }
+extern "C" int demo_gemm_desc_size(void) { return (int)sizeof(demo_gemm_desc); }
+
+extern "C" int demo_gemm(const demo_gemm_desc* dp, void* stream) {
+  DEMO_REQUIRE(dp != nullptr, "demo_gemm: null descriptor");
+  demo_gemm_desc d = *dp;
+  DEMO_REQUIRE(d.A && d.B && d.C, "demo_gemm: null operand");
+  DEMO_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "demo_gemm: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
+  DEMO_REQUIRE(d.batch1 >= 1 && d.batch2 >= 1 && (int64_t)d.batch1 * d.batch2 <= 65535, "demo_gemm: bad batch");
+  DEMO_REQUIRE((d.dtA == DEMO_F32 || d.dtA == DEMO_BF16) && (d.dtB == DEMO_F32 || d.dtB == DEMO_BF16) &&
+                   (d.dtC == DEMO_F32 || d.dtC == DEMO_BF16), "demo_gemm: bad dtype");
+  DEMO_REQUIRE(!(d.accumulate && d.dtC != DEMO_F32), "demo_gemm: accumulate needs fp32 C");
+  hipStream_t s = (hipStream_t)stream;
+  if (demo_gemm_bf16_eligible(d)) return demo_gemm_bf16(d, s);
+  return demo_gemm_generic(d, s);
+}

@@ -1,0 +1,95 @@
+// Shared device/host helpers for libdemo_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/demo_hip.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define DEMO_WAVE 64
+
+// ---- error plumbing ---------------------------------------------------------------------------
+extern thread_local char g_demo_err[512];
+#define DEMO_FAIL(code, ...)                                   \
+  do {                                                         \
+    snprintf(g_demo_err, sizeof(g_demo_err), __VA_ARGS__);     \
+    return (code);                                             \
+  } while (0)
+#define DEMO_REQUIRE(cond, ...)                \
+  do {                                         \
+    if (!(cond)) DEMO_FAIL(-1, __VA_ARGS__);   \
+  } while (0)
+#define DEMO_LAUNCH_CHECK(name)                                                        \
+  do {                                                                                 \
+    hipError_t e__ = hipGetLastError();                                                \
+    if (e__ != hipSuccess) DEMO_FAIL(-2, "%s: launch failed: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+// ---- bf16 <-> f32 -----------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// plain cast semantics (round-to-nearest-even, NaN stays NaN): hipcc emits v_cvt_pk_bf16_f32 at -O3
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, h);
+}
+
+template <typename T> struct io;
+template <> struct io<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+};
+template <> struct io<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+  static __device__ __forceinline__ float4 ld4(const bf16_t* p) {
+    uint2 r = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                       __uint_as_float(r.y & 0xffff0000u));
+  }
+  static __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+    uint2 r;
+    r.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+    r.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = r;
+  }
+};
+
+// ---- wave reductions (64 lanes) -----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- activations ---------------------------------------------------------------------------------
+__device__ __forceinline__ float act_apply(float x, int act) {
+  if (act == DEMO_ACT_QUICKGELU) return x / (1.0f + __expf(-1.702f * x));
+  if (act == DEMO_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+  return x;
+}
+__device__ __forceinline__ float act_grad(float x, int act) {
+  if (act == DEMO_ACT_QUICKGELU) {
+    float s = 1.0f / (1.0f + __expf(-1.702f * x));
+    return s * (1.0f + 1.702f * x * (1.0f - s));
+  }
+  if (act == DEMO_ACT_GELU) {
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+  }
+  return 1.0f;
+}
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

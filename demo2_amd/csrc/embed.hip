@@ -1,0 +1,285 @@
+// Patch gather (im2col), token assembly (+ln_pre), PIFE pooling, and small layout kernels.
+#include "common.h"
+
+namespace {
+
+// One thread per 4 consecutive kx of one (patch, c, ky): reads 16 B of the image row, writes 4 elements.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, T* __restrict__ cols, int Bn, int H,
+                                                     int W, int patch, int stride, int ny, int nx) {
+  const int pk = 3 * patch * patch;
+  const int q = patch >> 2;                               // float4 per patch row
+  const int64_t total = (int64_t)Bn * ny * nx * 3 * patch * q;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i;
+    const int kx4 = (int)(r % q); r /= q;
+    const int ky = (int)(r % patch); r /= patch;
+    const int c = (int)(r % 3); r /= 3;
+    const int px = (int)(r % nx); r /= nx;
+    const int py = (int)(r % ny); r /= ny;
+    const int b = (int)r;
+    const float* src = img + (((int64_t)b * 3 + c) * H + (py * stride + ky)) * W + px * stride + kx4 * 4;
+    float4 v;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) v = *reinterpret_cast<const float4*>(src);
+    else v = make_float4(src[0], src[1], src[2], src[3]);
+    T* dst = cols + ((int64_t)(b * ny + py) * nx + px) * pk + (c * patch + ky) * patch + kx4 * 4;
+    io<T>::st4(dst, v);
+  }
+}
+
+// One wave per token row.  W <= 2048.
+template <typename TP>
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const TP* __restrict__ patch, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, const float* __restrict__ cam_embed,
+                                                           const int64_t* __restrict__ cam, float cam_scale, int cam_all,
+                                                           const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                           float eps, float* __restrict__ x, float* __restrict__ pre,
+                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                           int Bn, int np, int W) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int L = np + 1;
+  if (row >= (int64_t)Bn * L) return;
+  const int b = (int)(row / L), t = (int)(row % L);
+  const int nv = W >> 2;
+  const float* ce = (cam_embed && cam) ? cam_embed + cam[b] * (int64_t)W : nullptr;
+  const bool add_cam = ce && (cam_all || t == 0);
+  float4 v[8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      float4 a;
+      if (t == 0) a = *reinterpret_cast<const float4*>(cls + c * 4);
+      else a = io<TP>::ld4(patch + ((int64_t)b * np + (t - 1)) * W + c * 4);
+      const float4 p = *reinterpret_cast<const float4*>(pos + (int64_t)t * W + c * 4);
+      a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+      if (add_cam) {
+        const float4 e = *reinterpret_cast<const float4*>(ce + c * 4);
+        a.x += cam_scale * e.x; a.y += cam_scale * e.y; a.z += cam_scale * e.z; a.w += cam_scale * e.w;
+      }
+      v[i] = a;
+      s += (a.x + a.y) + (a.z + a.w);
+      if (pre) *reinterpret_cast<float4*>(pre + row * W + c * 4) = a;
+    }
+  }
+  float* xr = x + row * W;
+  if (!ln_w) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) *reinterpret_cast<float4*>(xr + c * 4) = v[i];
+    }
+    return;
+  }
+  const float mean = wave_sum(s) / (float)W;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+      q += (a * a + bb * bb) + (cc * cc + dd * dd);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)W + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float4 g = *reinterpret_cast<const float4*>(ln_w + c * 4);
+      const float4 be = *reinterpret_cast<const float4*>(ln_b + c * 4);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + be.x;
+      o.y = (v[i].y - mean) * rstd * g.y + be.y;
+      o.z = (v[i].z - mean) * rstd * g.z + be.z;
+      o.w = (v[i].w - mean) * rstd * g.w + be.w;
+      *reinterpret_cast<float4*>(xr + c * 4) = o;
+    }
+  }
+}
+
+// z[b] = [tokens[b,0,:], mean_{i>=1} tokens[b,i,:]]; block per sample, thread per 4 channels.
+template <typename T>
+__global__ __launch_bounds__(256) void pife_pool_cat_kernel(const T* __restrict__ tok, float* __restrict__ z, int L, int C) {
+  const int b = blockIdx.x;
+  const T* tb = tok + (int64_t)b * L * C;
+  for (int c4 = threadIdx.x; c4 < (C >> 2); c4 += blockDim.x) {
+    const float4 g = io<T>::ld4(tb + c4 * 4);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = 1; l < L; ++l) {
+      const float4 v = io<T>::ld4(tb + (int64_t)l * C + c4 * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const float inv = 1.f / (float)(L - 1);
+    float* zr = z + (int64_t)b * 2 * C;
+    *reinterpret_cast<float4*>(zr + c4 * 4) = g;
+    *reinterpret_cast<float4*>(zr + C + c4 * 4) = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void set_token0_kernel(T* __restrict__ tok, const float* __restrict__ glob, int64_t ld, int L, int C) {
+  const int b = blockIdx.x;
+  for (int c4 = threadIdx.x; c4 < (C >> 2); c4 += blockDim.x)
+    io<T>::st4(tok + (int64_t)b * L * C + c4 * 4, *reinterpret_cast<const float4*>(glob + (int64_t)b * ld + c4 * 4));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void get_token0_kernel(const T* __restrict__ tok, float* __restrict__ out, int64_t ld, int L, int C) {
+  const int b = blockIdx.x;
+  for (int c4 = threadIdx.x; c4 < (C >> 2); c4 += blockDim.x)
+    *reinterpret_cast<float4*>(out + (int64_t)b * ld + c4 * 4) = io<T>::ld4(tok + (int64_t)b * L * C + c4 * 4);
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n4, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+    io<bf16_t>::st4(dst + i * 4, *reinterpret_cast<const float4*>(src + i * 4));
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int64_t i = n4 * 4; i < n; ++i) dst[i] = f2bf(src[i]);
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n4, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+    *reinterpret_cast<float4*>(dst + i * 4) = io<bf16_t>::ld4(src + i * 4);
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int64_t i = n4 * 4; i < n; ++i) dst[i] = bf2f(src[i]);
+}
+
+// 64x64 LDS-tiled transpose
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int rows, int cols) {
+  __shared__ T tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    if (r < rows && c < cols) tile[i][tx] = src[(int64_t)r * cols + c];
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < rows && c < cols) dst[(int64_t)c * rows + r] = tile[tx][i];
+  }
+}
+
+// column sums: grid (ceil(N/64), splits); each block sums a row slab, atomically adds into out.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, float* __restrict__ out, int M, int N, int64_t ldx,
+                                                     int rows_per_block) {
+  __shared__ float part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + tx;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  float s = 0.f;
+  if (n < N)
+    for (int r = r0 + ty; r < r1; r += 4) s += io<T>::ld(X + (int64_t)r * ldx + n);
+  part[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && n < N) atomicAdd(&out[n], part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+}
+
+inline unsigned grid_for(int64_t work, int block = 256, int cap = 256 * 8) {
+  int64_t g = cdiv64(work, block);
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int demo_im2col(const float* img, void* cols, int32_t Bn, int32_t H, int32_t W, int32_t patch, int32_t stride,
+                           int32_t dt, void* stream) {
+  DEMO_REQUIRE(patch % 4 == 0 && patch > 0 && stride > 0 && H >= patch && W >= patch, "demo_im2col: bad geometry");
+  const int ny = (H - patch) / stride + 1, nx = (W - patch) / stride + 1;
+  const int64_t total = (int64_t)Bn * ny * nx * 3 * patch * (patch / 4);
+  hipStream_t s = (hipStream_t)stream;
+  if (dt == DEMO_BF16)
+    hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, img, (bf16_t*)cols, Bn, H, W, patch, stride, ny, nx);
+  else
+    hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, img, (float*)cols, Bn, H, W, patch, stride, ny, nx);
+  DEMO_LAUNCH_CHECK("demo_im2col");
+  return 0;
+}
+
+extern "C" int demo_embed_tokens(const void* patch, int32_t dt_patch, const float* cls, const float* pos,
+                                 const float* cam_embed, const int64_t* cam, float cam_scale, int32_t cam_all_tokens,
+                                 const float* ln_w, const float* ln_b, float eps, float* x, float* pre, float* mean,
+                                 float* rstd, int32_t Bn, int32_t np, int32_t W, void* stream) {
+  DEMO_REQUIRE(W % 4 == 0 && W <= 2048, "demo_embed_tokens: W=%d unsupported", W);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)cdiv64((int64_t)Bn * (np + 1), 4));
+  if (dt_patch == DEMO_BF16)
+    hipLaunchKernelGGL(embed_tokens_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)patch, cls, pos, cam_embed, cam,
+                       cam_scale, cam_all_tokens, ln_w, ln_b, eps, x, pre, mean, rstd, Bn, np, W);
+  else
+    hipLaunchKernelGGL(embed_tokens_kernel<float>, grid, dim3(256), 0, s, (const float*)patch, cls, pos, cam_embed, cam,
+                       cam_scale, cam_all_tokens, ln_w, ln_b, eps, x, pre, mean, rstd, Bn, np, W);
+  DEMO_LAUNCH_CHECK("demo_embed_tokens");
+  return 0;
+}
+
+extern "C" int demo_pife_pool_cat(const void* tokens, int32_t dt, float* z, int32_t Bn, int32_t L, int32_t C, void* stream) {
+  DEMO_REQUIRE(C % 4 == 0 && L >= 2, "demo_pife_pool_cat: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  if (dt == DEMO_BF16) hipLaunchKernelGGL(pife_pool_cat_kernel<bf16_t>, dim3(Bn), dim3(128), 0, s, (const bf16_t*)tokens, z, L, C);
+  else hipLaunchKernelGGL(pife_pool_cat_kernel<float>, dim3(Bn), dim3(128), 0, s, (const float*)tokens, z, L, C);
+  DEMO_LAUNCH_CHECK("demo_pife_pool_cat");
+  return 0;
+}
+
+extern "C" int demo_set_token0(void* tokens, int32_t dt, const float* glob, int64_t glob_ld, int32_t Bn, int32_t L, int32_t C, void* stream) {
+  DEMO_REQUIRE(C % 4 == 0 && glob_ld % 4 == 0 && ((uintptr_t)glob & 15) == 0, "demo_set_token0: bad shape/alignment");
+  hipStream_t s = (hipStream_t)stream;
+  if (dt == DEMO_BF16) hipLaunchKernelGGL(set_token0_kernel<bf16_t>, dim3(Bn), dim3(128), 0, s, (bf16_t*)tokens, glob, glob_ld, L, C);
+  else hipLaunchKernelGGL(set_token0_kernel<float>, dim3(Bn), dim3(128), 0, s, (float*)tokens, glob, glob_ld, L, C);
+  DEMO_LAUNCH_CHECK("demo_set_token0");
+  return 0;
+}
+
+extern "C" int demo_get_token0(const void* tokens, int32_t dt, float* out, int64_t out_ld, int32_t Bn, int32_t L, int32_t C, void* stream) {
+  DEMO_REQUIRE(C % 4 == 0 && out_ld % 4 == 0 && ((uintptr_t)out & 15) == 0, "demo_get_token0: bad shape/alignment");
+  hipStream_t s = (hipStream_t)stream;
+  if (dt == DEMO_BF16) hipLaunchKernelGGL(get_token0_kernel<bf16_t>, dim3(Bn), dim3(128), 0, s, (const bf16_t*)tokens, out, out_ld, L, C);
+  else hipLaunchKernelGGL(get_token0_kernel<float>, dim3(Bn), dim3(128), 0, s, (const float*)tokens, out, out_ld, L, C);
+  DEMO_LAUNCH_CHECK("demo_get_token0");
+  return 0;
+}
+
+extern "C" int demo_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  DEMO_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0, "demo_cast_f32_bf16: misaligned");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n / 4, n);
+  DEMO_LAUNCH_CHECK("demo_cast_f32_bf16");
+  return 0;
+}
+extern "C" int demo_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream) {
+  DEMO_REQUIRE(((uintptr_t)dst & 15) == 0 && ((uintptr_t)src & 7) == 0, "demo_cast_bf16_f32: misaligned");
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, n / 4, n);
+  DEMO_LAUNCH_CHECK("demo_cast_bf16_f32");
+  return 0;
+}
+
+extern "C" int demo_transpose(const void* src, void* dst, int32_t rows, int32_t cols, int32_t dt, void* stream) {
+  dim3 grid((unsigned)cdiv64(cols, 64), (unsigned)cdiv64(rows, 64));
+  hipStream_t s = (hipStream_t)stream;
+  if (dt == DEMO_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, rows, cols);
+  else hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, s, (const float*)src, (float*)dst, rows, cols);
+  DEMO_LAUNCH_CHECK("demo_transpose");
+  return 0;
+}
+
+extern "C" int demo_colsum(const void* X, float* out, int32_t M, int32_t N, int64_t ldx, int32_t dt, int32_t accumulate, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s);
+    if (e != hipSuccess) DEMO_FAIL(-2, "demo_colsum: memset failed: %s", hipGetErrorString(e));
+  }
+  const int rows_per_block = 256;
+  dim3 grid((unsigned)cdiv64(N, 64), (unsigned)cdiv64(M, rows_per_block));
+  if (dt == DEMO_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, out, M, N, ldx, rows_per_block);
+  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)X, out, M, N, ldx, rows_per_block);
+  DEMO_LAUNCH_CHECK("demo_colsum");
+  return 0;
+}

@@ -1,0 +1,120 @@
+// Generic strided, two-level-batched GEMM with fp32 accumulation on the vector ALUs.
+// Serves (a) the fp32 parity mode, (b) every small / oddly shaped product of the path
+// (PIFE reduce, HDM folded keys and per-head value projections, ATMoE experts, classifiers),
+// (c) any transposition via strides.  The large bf16 products go to gemm_bf16.hip instead.
+#include "common.h"
+
+namespace {
+
+constexpr int GT = 64;   // output tile is GT x GT
+constexpr int GK = 16;   // k-step
+
+template <typename T> __device__ __forceinline__ float ldg(const void* p, int64_t i) {
+  return io<T>::ld(reinterpret_cast<const T*>(p) + i);
+}
+
+struct GArgs {
+  demo_gemm_desc d;
+};
+
+template <typename TA, typename TB, typename TC>
+__global__ __launch_bounds__(256) void gemm_generic_kernel(const GArgs args) {
+  const demo_gemm_desc& d = args.d;
+  __shared__ float As[GK][GT + 4];
+  __shared__ float Bs[GK][GT + 4];
+
+  const int z = blockIdx.z;
+  const int z1 = z / d.batch2, z2 = z % d.batch2;
+  const TA* A = reinterpret_cast<const TA*>(d.A) + z1 * d.sA1 + z2 * d.sA2;
+  const TB* B = reinterpret_cast<const TB*>(d.B) + z1 * d.sB1 + z2 * d.sB2;
+  const int64_t coff = z1 * d.sC1 + z2 * d.sC2;
+  TC* C = reinterpret_cast<TC*>(d.C) + coff;
+  const float* bias = d.bias ? d.bias + z1 * d.sBias1 + z2 * d.sBias2 : nullptr;
+  const float* res = d.residual ? d.residual + coff : nullptr;
+
+  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  const int t = threadIdx.x;
+  const int ty = t >> 4, tx = t & 15;   // 16 x 16 threads, 4x4 outputs each
+
+  // load mapping: walk the contiguous direction fastest
+  const bool a_kfast = (d.a_cs == 1) || (d.a_rs != 1);
+  const bool b_kfast = (d.b_cs == 1) || (d.b_rs != 1);
+
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+  for (int k0 = 0; k0 < d.K; k0 += GK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = t + i * 256;
+      int r, k;
+      if (a_kfast) { r = idx >> 4; k = idx & 15; } else { r = idx & 63; k = idx >> 6; }
+      const int gm = m0 + r, gk = k0 + k;
+      As[k][r] = (gm < d.M && gk < d.K) ? io<TA>::ld(A + (int64_t)gm * d.a_rs + (int64_t)gk * d.a_cs) : 0.f;
+      if (b_kfast) { r = idx >> 4; k = idx & 15; } else { r = idx & 63; k = idx >> 6; }
+      const int gn = n0 + r, gk2 = k0 + k;
+      Bs[k][r] = (gn < d.N && gk2 < d.K) ? io<TB>::ld(B + (int64_t)gn * d.b_rs + (int64_t)gk2 * d.b_cs) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GK; ++k) {
+      const float4 a = *reinterpret_cast<const float4*>(&As[k][ty * 4]);
+      const float4 b = *reinterpret_cast<const float4*>(&Bs[k][tx * 4]);
+      const float av[4] = {a.x, a.y, a.z, a.w};
+      const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gm = m0 + ty * 4 + i;
+    if (gm >= d.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gn = n0 + tx * 4 + j;
+      if (gn >= d.N) continue;
+      float v = acc[i][j] * d.alpha;
+      if (bias) v += bias[gn];
+      const int64_t ci = (int64_t)gm * d.c_rs + gn;
+      if (d.pre_out) io<TC>::st(reinterpret_cast<TC*>(d.pre_out) + coff + ci, v);
+      v = act_apply(v, d.act);
+      if (d.act_grad_pre) {
+        const float pre = d.dtPre == DEMO_BF16 ? ldg<bf16_t>(d.act_grad_pre, coff + ci) : ldg<float>(d.act_grad_pre, coff + ci);
+        v *= act_grad(pre, d.act_grad_kind);
+      }
+      if (res) v += res[ci];
+      if (d.accumulate) v += io<TC>::ld(C + ci);
+      io<TC>::st(C + ci, v);
+    }
+  }
+}
+
+template <typename TA, typename TB>
+int launch_c(const demo_gemm_desc& d, hipStream_t s) {
+  GArgs a;
+  a.d = d;
+  dim3 grid((unsigned)cdiv64(d.N, GT), (unsigned)cdiv64(d.M, GT), (unsigned)(d.batch1 * d.batch2));
+  if (d.dtC == DEMO_F32)
+    hipLaunchKernelGGL((gemm_generic_kernel<TA, TB, float>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((gemm_generic_kernel<TA, TB, bf16_t>), grid, dim3(256), 0, s, a);
+  DEMO_LAUNCH_CHECK("demo_gemm(generic)");
+  return 0;
+}
+
+}  // namespace
+
+int demo_gemm_generic(const demo_gemm_desc& d, hipStream_t s) {
+  if (d.dtA == DEMO_F32 && d.dtB == DEMO_F32) return launch_c<float, float>(d, s);
+  if (d.dtA == DEMO_BF16 && d.dtB == DEMO_BF16) return launch_c<bf16_t, bf16_t>(d, s);
+  if (d.dtA == DEMO_F32 && d.dtB == DEMO_BF16) return launch_c<float, bf16_t>(d, s);
+  return launch_c<bf16_t, float>(d, s);
+}

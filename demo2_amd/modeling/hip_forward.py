@@ -1,0 +1,225 @@
+"""Kernel schedule of the hot path: PIFE ViT trunk -> PIFE reduce -> HDM -> ATMoE -> BNNeck heads.
+
+Everything below is a fixed sequence of launches into libdemo_hip.so (demo2_amd/ops.py); there is no
+PyTorch arithmetic on the data path.  The three modalities share one trunk (make_model.py:247-249 of the
+reference), so they run as ONE batch of 3B images: exact, because the trunk has LayerNorm only.
+
+Data layout in HBM (B = samples, L = 1 + patches, W = trunk width, C = feat dim, T = compute dtype):
+  cols    (3B*np, 3*p*p) T      im2col patches, modality-major [RGB | NI | TI]
+  x       (3B*L, W)      fp32   residual stream (kept fp32 in both modes)
+  h/qkv/a/u (3B*L, .)    T      LayerNorm outputs, packed q|k|v, attention output, MLP hidden
+  tokens  (3B*L, C)      T      trunk output; row 0 of every image is later overwritten by the PIFE global
+  ori     (B, 3C)        fp32   [R_global | N_global | T_global]
+  feats   (B, 7, C)      fp32   HDM outputs == ATMoE query (B,7C) == ATMoE key stack (B,7,C)
+  moe     (B, 7C)        fp32   layout j*C + h*d + k   (AttnMOE.py:116-117)
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from .. import ops
+from ..ops import ACT_GELU, ACT_NONE, ACT_QUICKGELU
+
+Tensor = torch.Tensor
+BRANCHES = ("r", "n", "t", "rn", "rt", "nt", "rnt")
+NC_PAD = 128            # HDM score columns padded to the MFMA kernel's N granule
+
+
+class Tape:
+    """Activations kept for the backward pass (288 GB of HBM: nothing is recomputed)."""
+
+    def __init__(self):
+        self.blocks: List[dict] = []
+        self.d: Dict[str, object] = {}
+
+
+def trunk_forward(m, imgs: List[Tensor], cam: Optional[Tensor], T: torch.dtype, zero_mod=(), tape: Optional[Tape] = None) -> Tensor:
+    """Shared trunk over [RGB; NI; TI].  Returns tokens (3B*L, C) in dtype T.
+    CLIP: clip/model.py:446-484 + forward_ori :227-230.  ViT: vit_pytorch.py:415-434,173-190."""
+    g = m.geom
+    B = imgs[0].shape[0]
+    Bn, np_, L, W = 3 * B, g.n_patches, g.n_patches + 1, g.width
+    P = m.ptab
+    dev = imgs[0].device
+    # ---- K1: patch embedding = im2col + GEMM ---------------------------------------------------
+    cols = torch.empty(Bn * np_, 3 * g.patch * g.patch, device=dev, dtype=T)
+    for i, im in enumerate(imgs):
+        sl = cols[i * B * np_:(i + 1) * B * np_]
+        if i in zero_mod:
+            sl.zero_()                                    # eval-time missing modality (make_model.py:233-239)
+        else:
+            ops.im2col_into(im, sl, g.patch, g.stride)
+    wconv = P.w(g.k_conv, T).view(W, -1)
+    patch = ops.gemm(cols, wconv, bias=P.f(g.k_conv_bias) if g.k_conv_bias else None)
+    # ---- K2: cls/pos/SIE (+ ln_pre) ----------------------------------------------------------------
+    cam3 = cam.repeat(3) if (cam is not None and g.cam_embed) else None
+    emb = ops.embed_tokens(patch, P.f(g.k_cls).view(-1), P.f(g.k_pos).view(L, W), P.f(g.cam_embed).view(-1, W) if g.cam_embed else None,
+                           cam3, g.sie_coe, g.cam_all_tokens, P.f(g.k_lnpre + ".weight") if g.k_lnpre else None,
+                           P.f(g.k_lnpre + ".bias") if g.k_lnpre else None, g.ln_eps, Bn, np_, save=tape is not None)
+    if tape is not None:
+        x, pre, mean, rstd = emb
+        tape.d.update(cols=cols, emb_pre=pre, emb_mean=mean, emb_rstd=rstd, cam3=cam3)
+    else:
+        x = emb
+    act = ACT_QUICKGELU if g.arch == "clip" else ACT_GELU
+    # ---- K3-K6: transformer blocks -------------------------------------------------------------------
+    for i in range(g.layers):
+        k = g.block_keys(i)
+        sv = tape is not None
+        r1 = ops.layernorm_fwd(x, P.f(k["ln1"] + ".weight"), P.f(k["ln1"] + ".bias"), g.ln_eps, T, save=sv)
+        h1 = r1[0] if sv else r1
+        qkv = ops.gemm(h1, P.w(k["qkv_w"], T), bias=P.f(k["qkv_b"]))
+        r2 = ops.attention_fwd(qkv, Bn, L, g.heads, save_lse=sv)
+        a = r2[0] if sv else r2
+        x1 = ops.gemm(a, P.w(k["proj_w"], T), bias=P.f(k["proj_b"]), residual=x, out=None if sv else x, out_dtype=torch.float32)
+        r3 = ops.layernorm_fwd(x1, P.f(k["ln2"] + ".weight"), P.f(k["ln2"] + ".bias"), g.ln_eps, T, save=sv)
+        h2 = r3[0] if sv else r3
+        if sv:
+            pre = torch.empty(Bn * L, 4 * W, device=dev, dtype=T)
+            u = ops.gemm(h2, P.w(k["fc1_w"], T), bias=P.f(k["fc1_b"]), act=act, pre_out=pre)
+        else:
+            pre = None
+            u = ops.gemm(h2, P.w(k["fc1_w"], T), bias=P.f(k["fc1_b"]), act=act)
+        x2 = ops.gemm(u, P.w(k["fc2_w"], T), bias=P.f(k["fc2_b"]), residual=x1, out=None if sv else x1, out_dtype=torch.float32)
+        if sv:
+            tape.blocks.append(dict(x=x, mean1=r1[1], rstd1=r1[2], h1=h1, qkv=qkv, lse=r2[1], a=a, x1=x1, mean2=r3[1], rstd2=r3[2],
+                                    h2=h2, pre=pre, u=u))
+        x = x2
+    # ---- K7: final LayerNorm (+ CLIP projection) ---------------------------------------------------------
+    sv = tape is not None
+    rf = ops.layernorm_fwd(x, P.f(g.k_lnpost + ".weight"), P.f(g.k_lnpost + ".bias"), g.ln_eps, T, save=sv)
+    y = rf[0] if sv else rf
+    if g.arch == "clip":
+        tokens = ops.gemm(y, P.w_t(g.k_proj, T))          # (3B*L, C) = y @ proj ; proj stored (W, C)
+    else:
+        tokens = y
+    if sv:
+        tape.d.update(x_final=x, meanf=rf[1], rstdf=rf[2], y=y)
+    return tokens
+
+
+def pife_forward(m, tokens: Tensor, B: int, tape: Optional[Tape] = None) -> Tensor:
+    """PIFE global-local reduce for the three modalities (make_model.py:52-58,301-303) -> ori (B, 3C) fp32.
+    Without GLOBAL_LOCAL the globals are the cls rows."""
+    g = m.geom
+    L, C = g.n_patches + 1, g.feat_dim
+    P = m.ptab
+    dev = tokens.device
+    ori = torch.empty(B, 3 * C, device=dev, dtype=torch.float32)
+    if not g.global_local:
+        for i in range(3):
+            ops.get_token0(tokens[i * B * L:(i + 1) * B * L], ori, i * C, 3 * C, B, L)
+        return ori
+    z = ops.pife_pool_cat(tokens, 3 * B, L)                                   # (3B, 2C) fp32
+    zl = torch.empty(3 * B, 2 * C, device=dev, dtype=torch.float32)
+    stats = []
+    for i, name in enumerate(("rgb_reduce", "nir_reduce", "tir_reduce")):
+        r = ops.layernorm_fwd(z[i * B:(i + 1) * B], P.f(name + ".0.weight"), P.f(name + ".0.bias"), 1e-5, torch.float32,
+                              save=tape is not None, out=zl[i * B:(i + 1) * B])
+        if tape is not None:
+            stats.append((r[1], r[2]))
+    # one grouped GEMM for the three reduce layers (their parameters are equally spaced in the flat buffer)
+    s_w = P.stride("rgb_reduce.1.weight", "nir_reduce.1.weight", "tir_reduce.1.weight")
+    s_b = P.stride("rgb_reduce.1.bias", "nir_reduce.1.bias", "tir_reduce.1.bias")
+    pre = torch.empty(B, 3 * C, device=dev, dtype=torch.float32) if tape is not None else None
+    ops.gemm_raw(zl, P.flat, ori, B, C, 2 * C, 2 * C, 1, 2 * C, 1, 3 * C, b_off=P.off("rgb_reduce.1.weight"),
+                 bias=P.flat, bias_off=P.off("rgb_reduce.1.bias"), act=ACT_QUICKGELU, batch1=3, batch2=1,
+                 sA=(B * 2 * C, 0), sB=(s_w, 0), sC=(C, 0), sBias=(s_b, 0), pre_out=pre)
+    if tape is not None:
+        tape.d.update(pife_z=z, pife_zl=zl, pife_stats=stats, pife_pre=pre)
+    return ori
+
+
+def hdm_forward(m, tokens: Tensor, ori: Tensor, B: int, training: bool, tape: Optional[Tape] = None) -> Tensor:
+    """HDM (AttnMOE.py:153-191) in the folded single-query form (see csrc/fusion.hip) -> feats (B,7,C) fp32."""
+    g = m.geom
+    L, C, Hh = g.n_patches + 1, g.feat_dim, g.hdm_heads
+    P = m.ptab
+    dev = tokens.device
+    f = "generalFusion."
+    T = tokens.dtype
+    # the reduced globals replace the cls rows of the key/value streams (AttnMOE.py:155-165)
+    for i in range(3):
+        ops.set_token0(tokens[i * B * L:(i + 1) * B * L], ori, i * C, 3 * C, B, L)
+    sbr_w = P.stride(*[f + b + ".in_proj_weight" for b in BRANCHES])
+    sbr_b = P.stride(*[f + b + ".in_proj_bias" for b in BRANCHES])
+    sbr_ow = P.stride(*[f + b + ".out_proj.weight" for b in BRANCHES])
+    sbr_ob = P.stride(*[f + b + ".out_proj.bias" for b in BRANCHES])
+    s_tok = P.stride(*[f + b + "_token" for b in BRANCHES])
+    o_w, o_b = P.off(f + "r.in_proj_weight"), P.off(f + "r.in_proj_bias")
+    # q[br] = Wq tok + bq  (batch independent)
+    q = torch.empty(7, C, device=dev, dtype=torch.float32)
+    ops.gemm_raw(P.flat, P.flat, q, 1, C, C, C, 1, C, 1, C, a_off=P.off(f + "r_token"), b_off=o_w, bias=P.flat, bias_off=o_b,
+                 batch1=7, sA=(s_tok, 0), sB=(sbr_w, 0), sC=(C, 0), sBias=(sbr_b, 0))
+    # folded keys U[br,h,:] = dh^-0.5 * Wk_h^T q_h   -> rows of a (NC_PAD, C) T matrix, zero padded
+    U = m.workspace("hdm_U", (NC_PAD, C), T, zero=True)
+    ops.gemm_raw(q, P.flat, U, 1, C, 64, C, 1, 1, C, C, b_off=o_w + C * C, alpha=64 ** -0.5, batch1=7, batch2=Hh,
+                 sA=(C, 64), sB=(sbr_w, 64 * C), sC=(Hh * C, C))
+    S = ops.gemm(tokens, U, out_dtype=torch.float32)                              # (3B*L, NC_PAD)
+    p_drop = g.hdm_dropout if training else 0.0
+    seed = m.next_seed() if p_drop > 0 else 0
+    pooled, psum, probs = ops.hdm_softmax_pool(S, tokens, B, L, C, Hh, NC_PAD, p_drop, seed, save_probs=tape is not None)
+    # per-head value projection o[b,br,h*64+e] = Wv_h pooled[b,br,h,:] (+ bv * psum)
+    o = torch.empty(B, 7, C, device=dev, dtype=torch.float32)
+    ops.gemm_raw(pooled, P.flat, o, B, 64, C, 7 * Hh * C, 1, C, 1, 7 * C, b_off=o_w + 2 * C * C,
+                 bias=P.flat if p_drop == 0 else None, bias_off=o_b + 2 * C, batch1=7, batch2=Hh,
+                 sA=(Hh * C, C), sB=(sbr_w, 64 * C), sC=(C, 64), sBias=(sbr_b, 64))
+    if p_drop > 0:
+        ops.hdm_vbias(o, P.flat, o_b + 2 * C, sbr_b, psum, B, C, Hh)
+    feats = torch.empty(B, 7, C, device=dev, dtype=torch.float32)
+    ops.gemm_raw(o, P.flat, feats, B, C, C, 7 * C, 1, C, 1, 7 * C, b_off=P.off(f + "r.out_proj.weight"), bias=P.flat,
+                 bias_off=P.off(f + "r.out_proj.bias"), batch1=7, sA=(C, 0), sB=(sbr_ow, 0), sC=(C, 0), sBias=(sbr_ob, 0))
+    if tape is not None:
+        tape.d.update(hdm_q=q, hdm_U=U, hdm_probs=probs, hdm_pooled=pooled, hdm_psum=psum, hdm_o=o, hdm_seed=seed,
+                      hdm_pdrop=p_drop, tokens=tokens)
+    return feats
+
+
+def atmoe_forward(m, feats: Tensor, B: int, training: bool, tape: Optional[Tape] = None) -> Tensor:
+    """ATMoE (AttnMOE.py:94-121): attention gate over the 7 features + 7*H per-chunk experts -> (B, 7C) fp32."""
+    g = m.geom
+    C, H = g.feat_dim, g.moe_head
+    d = C // H
+    P, S = m.ptab, m.stab
+    dev = feats.device
+    gk = "generalFusion.moe.gating_network.gate."
+    x1 = ops.gemm(feats.view(B, 7 * C), P.f(gk + "linear_re.0.weight"), bias=P.f(gk + "linear_re.0.bias"), act=ACT_QUICKGELU,
+                  pre_out_new=tape is not None)
+    x1, x1_pre = x1 if tape is not None else (x1, None)
+    bn1 = ops.batchnorm_fwd(x1, P.f(gk + "linear_re.2.weight"), P.f(gk + "linear_re.2.bias"), S.f(gk + "linear_re.2.running_mean"),
+                            S.f(gk + "linear_re.2.running_var"), training, g.bn_momentum, g.bn_eps, save=tape is not None)
+    x2 = bn1[0] if tape is not None else bn1
+    qg = ops.gemm(x2, P.f(gk + "q_.weight"))
+    kg = ops.gemm(feats.view(B * 7, C), P.f(gk + "k_.weight"))
+    gates = ops.atmoe_gate_softmax(qg, kg, B, C, H)
+    e0 = "generalFusion.moe.experts.0.expertHead.0.mlp."
+    e1 = "generalFusion.moe.experts.0.expertHead.1.mlp."
+    es_w = P.off(e1 + "0.weight") - P.off(e0 + "0.weight")
+    y = torch.empty(B, 7 * C, device=dev, dtype=torch.float32)
+    ypre = torch.empty(B, 7 * C, device=dev, dtype=torch.float32) if tape is not None else None
+    ops.gemm_raw(feats, P.flat, y, B, d, d, 7 * C, 1, d, 1, 7 * C, b_off=P.off(e0 + "0.weight"), bias=P.flat,
+                 bias_off=P.off(e0 + "0.bias"), act=ACT_QUICKGELU, batch1=H, batch2=7, sA=(d, C), sB=(7 * es_w, es_w),
+                 sC=(d, C), sBias=(7 * es_w, es_w), pre_out=ypre)
+    ss = S.off(e1 + "2.running_mean") - S.off(e0 + "2.running_mean")
+    bn2 = ops.batchnorm_fwd(y, P.f(e0 + "2.weight"), P.f(e0 + "2.bias"), S.f(e0 + "2.running_mean"), S.f(e0 + "2.running_var"),
+                            training, g.bn_momentum, g.bn_eps, save=tape is not None, group=(d, H, 7, es_w, ss), gate=gates)
+    moe = bn2[0] if tape is not None else bn2
+    if tape is not None:
+        tape.d.update(at_x1=x1, at_x1pre=x1_pre, at_bn1=bn1[1:], at_x2=x2, at_q=qg, at_k=kg, at_gates=gates, at_y=y, at_ypre=ypre,
+                      at_bn2=bn2[1:], feats=feats)
+    return moe
+
+
+def head_forward(m, x: Tensor, bn: str, cls: str, training: bool, tape: Optional[Tape] = None, tag: str = "") -> Tensor:
+    """classifier(bottleneck(x)) (make_model.py:134-138,174-194) -> logits (B, classes) fp32."""
+    P, S = m.ptab, m.stab
+    g = m.geom
+    r = ops.batchnorm_fwd(x, P.f(bn + ".weight"), P.f(bn + ".bias"), S.f(bn + ".running_mean"), S.f(bn + ".running_var"), training,
+                          g.bn_momentum, g.bn_eps, save=tape is not None)
+    xb = r[0] if tape is not None else r
+    score = ops.gemm(xb, P.f(cls + ".weight"))
+    if tape is not None:
+        tape.d["head_" + tag] = dict(x=x, xb=xb, stats=r[1:], bn=bn, cls=cls)
+    return score

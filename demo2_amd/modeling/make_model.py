@@ -1,0 +1,379 @@
+"""Model assembly with the reference's call surface (reference: modeling/make_model.py).
+
+    model = make_model(cfg, num_class, camera_num, view_num)
+    train:  model(img_dict, label=, cam_label=, view_label=) -> (moe_score, moe_feat, ori_score, ori, loss_moe) [DIRECT=1]
+    eval :  model(img_dict, cam_label=, view_label=, return_pattern=1|2|3) -> (B, D) features
+
+State-dict names are the reference's (so its .pth files load via load_param); the arithmetic is the HIP kernel
+schedule in hip_forward.py.  In this fork of the reference the HDM/ATMoE wiring exists only as constructor code
+(make_model.py:131-138) plus documentation; the forward below re-instates it exactly as SURVEY.md section 3.2
+reconstructs it: backbone x3 (make_model.py:247-249) -> PIFE reduce (:301-303) -> ori (:370) -> GeneralFusion
+(AttnMOE.py:202-224) -> BNNeck heads (:134-138,174-194).  return_pattern 3 concatenates [ori, moe]
+(reference drawing/DeMo_overall_diagram_prompt.md:153-155; the order does not change distances / mAP).
+
+MI355X-first memory layout: every parameter is a view into ONE flat fp32 buffer (and every float buffer into one
+flat stats buffer); gradients accumulate into one flat fp32 buffer of the same layout, so data-parallel
+reduction is a handful of large RCCL calls on contiguous memory, and the bf16 weight shadow used by the MFMA
+GEMMs is refreshed by a single cast launch after each optimizer step.
+"""
+from __future__ import annotations
+
+import os
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import DemoHipError
+from . import hip_forward as HF
+from .backbones.vit_pytorch import _Holder, vit_base_patch16_224
+from .meta_arch import build_transformer, weights_init_classifier, weights_init_kaiming
+from .moe.AttnMOE import GeneralFusion, QuickGELU
+
+ALIGN = 64  # elements; keeps every parameter 256-B aligned in the fp32 buffer (128 B in the bf16 shadow)
+
+
+class FlatTable:
+    """name -> (offset, shape) inside one flat buffer; hands out typed views."""
+
+    def __init__(self):
+        self.flat: Optional[torch.Tensor] = None
+        self.shadow: Optional[torch.Tensor] = None          # bf16 copy of `flat`
+        self.index: Dict[str, tuple] = {}
+        self.extra: Dict[str, torch.Tensor] = {}             # derived tensors (transposed shadows)
+        self.shadow_version = -1
+
+    def off(self, name: str) -> int:
+        return self.index[name][0]
+
+    def f(self, name: str) -> torch.Tensor:
+        o, shape, n = self.index[name]
+        return self.flat[o:o + n].view(shape)
+
+    def w(self, name: str, T: torch.dtype) -> torch.Tensor:
+        if T == torch.float32:
+            return self.f(name)
+        o, shape, n = self.index[name]
+        return self.shadow[o:o + n].view(shape)
+
+    def w_t(self, name: str, T: torch.dtype) -> torch.Tensor:
+        """2-D parameter transposed and contiguous, dtype T (refreshed with the shadow)."""
+        return self.extra[(name, T)]
+
+    def stride(self, *names) -> int:
+        offs = [self.off(n) for n in names]
+        d = {b - a for a, b in zip(offs, offs[1:])}
+        if len(d) != 1:
+            raise DemoHipError(f"parameters {names} are not equally spaced in the flat buffer: {offs}")
+        return d.pop()
+
+
+def _layout(named) -> tuple:
+    index, total = {}, 0
+    for name, t in named:
+        n = t.numel()
+        index[name] = (total, tuple(t.shape), n)
+        total += (n + ALIGN - 1) // ALIGN * ALIGN
+    return index, max(total, ALIGN)
+
+
+class DeMo(_Holder):
+    def __init__(self, num_classes, cfg, camera_num, view_num, factory):
+        super().__init__()
+        for flag in ("USE_SACR", "USE_SDTPS", "USE_LIF", "USE_DGAF", "USE_MULTIMODAL_SACR"):
+            if getattr(cfg.MODEL, flag, False):
+                raise NotImplementedError(f"MODEL.{flag}: alternative fusion modules are outside the PIFE->HDM->ATMoE hot path "
+                                          "(SURVEY.md section 2, rows 5/13/14)")
+        if 'vit_base_patch16_224' in cfg.MODEL.TRANSFORMER_TYPE:
+            self.feat_dim = getattr(cfg.MODEL, 'TRUNK_WIDTH', 768)
+        elif 'ViT-B-16' in cfg.MODEL.TRANSFORMER_TYPE:
+            self.feat_dim = getattr(cfg.MODEL, 'TRUNK_OUT_DIM', 512)
+        else:
+            raise NotImplementedError(cfg.MODEL.TRANSFORMER_TYPE)
+        self.BACKBONE = build_transformer(num_classes, cfg, camera_num, view_num, factory, feat_dim=self.feat_dim)
+        self.num_classes = num_classes
+        self.cfg = cfg
+        self.camera, self.view = camera_num, view_num
+        self.direct = cfg.MODEL.DIRECT
+        self.image_size = cfg.INPUT.SIZE_TRAIN
+        self.miss_type = cfg.TEST.MISS
+        self.HDM, self.ATM = cfg.MODEL.HDM, cfg.MODEL.ATM
+        self.GLOBAL_LOCAL = cfg.MODEL.GLOBAL_LOCAL
+        self.head = cfg.MODEL.HEAD
+        C = self.feat_dim
+        # PIFE reduce layers (make_model.py:52-58)
+        self.rgb_reduce = nn.Sequential(nn.LayerNorm(2 * C), nn.Linear(2 * C, C), QuickGELU())
+        self.nir_reduce = nn.Sequential(nn.LayerNorm(2 * C), nn.Linear(2 * C, C), QuickGELU())
+        self.tir_reduce = nn.Sequential(nn.LayerNorm(2 * C), nn.Linear(2 * C, C), QuickGELU())
+        if self.HDM or self.ATM:                                        # make_model.py:131-138
+            if not self.HDM:
+                raise NotImplementedError("ATM without HDM has no defined forward in the reference (AttnMOE.py:202-224)")
+            self.generalFusion = GeneralFusion(feat_dim=C, num_experts=7, head=self.head, reg_weight=0, cfg=cfg)
+            self.classifier_moe = nn.Linear(7 * C, num_classes, bias=False)
+            self.classifier_moe.apply(weights_init_classifier)
+            self.bottleneck_moe = nn.BatchNorm1d(7 * C)
+            self.bottleneck_moe.bias.requires_grad_(False)
+            self.bottleneck_moe.apply(weights_init_kaiming)
+        if self.direct:                                                  # make_model.py:174-179
+            self.classifier = nn.Linear(3 * C, num_classes, bias=False)
+            self.classifier.apply(weights_init_classifier)
+            self.bottleneck = nn.BatchNorm1d(3 * C)
+            self.bottleneck.bias.requires_grad_(False)
+            self.bottleneck.apply(weights_init_kaiming)
+        else:                                                            # make_model.py:181-194
+            for s in "rnt":
+                cls = nn.Linear(C, num_classes, bias=False)
+                cls.apply(weights_init_classifier)
+                bn = nn.BatchNorm1d(C)
+                bn.bias.requires_grad_(False)
+                if s != "t":
+                    bn.apply(weights_init_kaiming)
+                setattr(self, "classifier_" + s, cls)
+                setattr(self, "bottleneck_" + s, bn)
+        self.compute_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[os.environ.get("DEMO_COMPUTE_DTYPE", "bf16")]
+        self.ptab, self.stab = FlatTable(), FlatTable()
+        self._ws: Dict[str, torch.Tensor] = {}
+        self._seed = 0x5EED
+        self._plist = None
+        self.geom = self._make_geometry(cfg)
+        self._flatten()
+
+    # ------------------------------------------------------------------ geometry / key names
+    def _make_geometry(self, cfg):
+        b = self.BACKBONE
+        g = SimpleNamespace()
+        g.arch = "clip" if b.clip else "vit"
+        base = b.base
+        g.patch = 16
+        sh, sw = cfg.MODEL.STRIDE_SIZE
+        if sh != sw:
+            raise NotImplementedError("anisotropic patch stride")
+        g.stride = sh
+        h, w = cfg.INPUT.SIZE_TRAIN
+        g.n_patches = ((h - 16) // sh + 1) * ((w - 16) // sw + 1)
+        g.feat_dim, g.moe_head, g.hdm_heads = self.feat_dim, self.head, self.feat_dim // 64
+        g.global_local = bool(self.GLOBAL_LOCAL)
+        g.hdm_dropout = 0.1
+        g.bn_eps, g.bn_momentum = 1e-5, 0.1
+        g.sie_coe = float(cfg.MODEL.SIE_COE)
+        p = "BACKBONE.base."
+        if g.arch == "clip":
+            g.width, g.layers, g.heads = base.width, base.layers, base.heads
+            g.ln_eps = 1e-5
+            g.k_conv, g.k_conv_bias = p + "conv1.weight", None
+            g.k_cls, g.k_pos = p + "class_embedding", p + "positional_embedding"
+            g.k_lnpre, g.k_lnpost, g.k_proj = p + "ln_pre", p + "ln_post", p + "proj"
+            g.cam_embed = "BACKBONE.cv_embed" if hasattr(b, "cv_embed") else None
+            g.cam_all_tokens = False
+
+            def block_keys(i, p=p):
+                q = f"{p}transformer.resblocks.{i}."
+                return dict(ln1=q + "ln_1", qkv_w=q + "attn.in_proj_weight", qkv_b=q + "attn.in_proj_bias",
+                            proj_w=q + "attn.out_proj.weight", proj_b=q + "attn.out_proj.bias", ln2=q + "ln_2",
+                            fc1_w=q + "mlp.c_fc.weight", fc1_b=q + "mlp.c_fc.bias", fc2_w=q + "mlp.c_proj.weight",
+                            fc2_b=q + "mlp.c_proj.bias")
+        else:
+            g.width, g.layers, g.heads = base.embed_dim, base.depth, base.num_heads
+            g.ln_eps = base.eps
+            g.k_conv, g.k_conv_bias = p + "patch_embed.proj.weight", p + "patch_embed.proj.bias"
+            g.k_cls, g.k_pos = p + "cls_token", p + "pos_embed"
+            g.k_lnpre, g.k_lnpost, g.k_proj = None, p + "norm", None
+            g.cam_embed = p + "sie_embed" if hasattr(base, "sie_embed") else None
+            g.cam_all_tokens = True
+            g.sie_coe = float(base.sie_xishu)
+
+            def block_keys(i, p=p):
+                q = f"{p}blocks.{i}."
+                return dict(ln1=q + "norm1", qkv_w=q + "attn.qkv.weight", qkv_b=q + "attn.qkv.bias", proj_w=q + "attn.proj.weight",
+                            proj_b=q + "attn.proj.bias", ln2=q + "norm2", fc1_w=q + "mlp.fc1.weight", fc1_b=q + "mlp.fc1.bias",
+                            fc2_w=q + "mlp.fc2.weight", fc2_b=q + "mlp.fc2.bias")
+        g.block_keys = block_keys
+        if g.width // g.heads != 64:
+            raise NotImplementedError("attention kernels are specialised for head dim 64")
+        return g
+
+    # ------------------------------------------------------------------ flat storage
+    def _flatten(self):
+        """(Re)pack parameters and float buffers into the flat buffers on their current device."""
+        params = list(self.named_parameters())
+        dev = params[0][1].device
+        index, total = _layout(params)
+        flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for name, p in params:
+                o, shape, n = index[name]
+                flat[o:o + n].copy_(p.detach().reshape(-1).float())
+                p.data = flat[o:o + n].view(shape)
+        self.ptab.flat, self.ptab.index = flat, index
+        self.ptab.shadow, self.ptab.shadow_version, self.ptab.extra = None, -1, {}
+        bufs = [(n, b) for n, b in self.named_buffers() if b.is_floating_point()]
+        sindex, stotal = _layout(bufs)
+        sflat = torch.zeros(stotal, device=dev, dtype=torch.float32)
+        mods = dict(self.named_modules())
+        with torch.no_grad():
+            for name, b in bufs:
+                o, shape, n = sindex[name]
+                sflat[o:o + n].copy_(b.reshape(-1).float())
+                mname, _, attr = name.rpartition(".")
+                mods[mname]._buffers[attr] = sflat[o:o + n].view(shape)
+        self.stab.flat, self.stab.index = sflat, sindex
+        # int64 counters (BatchNorm num_batches_tracked) share one flat tensor: one add per training step
+        ibufs = [(n, b) for n, b in self.named_buffers() if not b.is_floating_point()]
+        iflat = torch.zeros(max(len(ibufs), 1), device=dev, dtype=torch.int64)
+        with torch.no_grad():
+            for i, (name, b) in enumerate(ibufs):
+                iflat[i] = b.reshape(-1)[0].to(torch.int64)
+                mname, _, attr = name.rpartition(".")
+                mods[mname]._buffers[attr] = iflat[i]
+        self._nbt_flat = iflat
+        self._grad_flat = None
+        self._ws = {}
+        self._plist = None
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        self._flatten()
+        return self
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        r = super().load_state_dict(state_dict, strict=strict, assign=False)   # copies into the flat views
+        self.ptab.shadow_version = -1
+        return r
+
+    def grad_buffer(self) -> torch.Tensor:
+        """Flat fp32 gradient buffer with the parameter layout; every p.grad is a view into it."""
+        if self._grad_flat is None or self._grad_flat.device != self.ptab.flat.device:
+            self._grad_flat = torch.zeros_like(self.ptab.flat)
+        return self._grad_flat
+
+    def attach_grads(self, zero: bool = True):
+        gflat = self.grad_buffer()
+        if zero:
+            gflat.zero_()
+        for name, p in self.named_parameters():
+            if p.requires_grad:
+                o, shape, n = self.ptab.index[name]
+                p.grad = gflat[o:o + n].view(shape)
+
+    def _param_version(self) -> int:
+        if self._plist is None:
+            self._plist = [p for p in self.parameters()]
+        return sum(p._version for p in self._plist)
+
+    def refresh_shadow(self):
+        """Compute-dtype copies of the weights (bf16 shadow for the MFMA GEMMs, transposed CLIP proj);
+        one cast launch whenever any parameter changed in place (optimizer step, load_state_dict)."""
+        P, T = self.ptab, self.compute_dtype
+        ver = self._param_version()
+        if P.shadow_version == ver and (T != torch.bfloat16 or P.shadow is not None):
+            return
+        if T == torch.bfloat16:
+            if P.shadow is None:
+                P.shadow = torch.empty(P.flat.numel(), device=P.flat.device, dtype=torch.bfloat16)
+            ops.cast_f32_bf16(P.flat, P.shadow)
+        if self.geom.k_proj:
+            P.extra[(self.geom.k_proj, T)] = ops.transpose(P.w(self.geom.k_proj, T))
+        P.shadow_version = ver
+
+    def workspace(self, name, shape, dtype, zero=False) -> torch.Tensor:
+        key = (name, tuple(shape), dtype)
+        t = self._ws.get(key)
+        if t is None or t.device != self.ptab.flat.device:
+            t = (torch.zeros if zero else torch.empty)(*shape, device=self.ptab.flat.device, dtype=dtype)
+            self._ws[key] = t
+        return t
+
+    def next_seed(self) -> int:
+        self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) & (2 ** 64 - 1)
+        return self._seed
+
+    def set_compute_dtype(self, dtype: torch.dtype):
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.compute_dtype = dtype
+        self.ptab.shadow_version = -1
+        return self
+
+    # ------------------------------------------------------------------ reference surface
+    def load_param(self, trained_path):                                 # make_model.py:196-200
+        state_dict = torch.load(trained_path, map_location="cpu", weights_only=True)
+        print("Successfully load ckpt!")
+        print(self.load_state_dict(state_dict, strict=False))
+
+    def flops(self, shape=(3, 256, 128)):
+        """Algorithmic forward FLOPs of one triplet (2*M*N*K convention);
+        the reference counts with fvcore (make_model.py:202-222), which is not available offline."""
+        g = self.geom
+        L, W, C = g.n_patches + 1, g.width, g.feat_dim
+        blk = 2 * L * W * 3 * W + 4 * L * L * W + 2 * L * W * W + 16 * L * W * W
+        img = g.layers * blk + 2 * g.n_patches * W * 3 * 256 + (2 * L * W * C if g.arch == "clip" else 0)
+        return 3 * img
+
+    def forward(self, x, label=None, cam_label=None, view_label=None, return_pattern=3, img_path=None):
+        RGB, NI, TI = x['RGB'], x['NI'], x['TI']
+        if not RGB.is_cuda:
+            raise DemoHipError("DeMo.forward needs HIP device tensors: the product path has no CPU fallback "
+                               "(the CPU oracle lives in oracle/ and is test infrastructure)")
+        if 'cam_label' in x:
+            cam_label = x['cam_label']
+        zero_mod = ()
+        if not self.training:                                            # make_model.py:233-239
+            zero_mod = {'r': (0,), 'n': (1,), 't': (2,), 'rn': (0, 1), 'rt': (0, 2), 'nt': (1, 2)}.get(self.miss_type, ())
+        imgs = [t.contiguous().float() for t in (RGB, NI, TI)]
+        if cam_label is not None and not torch.is_tensor(cam_label):
+            cam_label = torch.full((imgs[0].shape[0],), int(cam_label), dtype=torch.int64, device=imgs[0].device)
+        if cam_label is not None:
+            cam_label = cam_label.to(device=imgs[0].device, dtype=torch.int64)
+        self.refresh_shadow()
+        if self.training and torch.is_grad_enabled():
+            from .hip_backward import train_forward
+            return train_forward(self, imgs, cam_label)
+        return self._forward_nograd(imgs, cam_label, zero_mod, return_pattern)
+
+    def _forward_nograd(self, imgs, cam, zero_mod, return_pattern, training=None):
+        training = self.training if training is None else training
+        B = imgs[0].shape[0]
+        tokens = HF.trunk_forward(self, imgs, cam, self.compute_dtype, zero_mod)
+        ori = HF.pife_forward(self, tokens, B)
+        moe = None
+        if self.HDM:
+            feats = HF.hdm_forward(self, tokens, ori, B, training)
+            moe = HF.atmoe_forward(self, feats, B, training) if self.ATM else feats.view(B, -1)
+        if training:
+            return self._train_outputs(ori, moe, None)
+        if moe is None or return_pattern == 1:
+            return ori
+        if return_pattern == 2:
+            return moe
+        return torch.cat([ori, moe], dim=-1)
+
+    def _train_outputs(self, ori, moe, tape):
+        C = self.feat_dim
+        out = ()
+        if moe is not None:
+            out += (HF.head_forward(self, moe, "bottleneck_moe", "classifier_moe", True, tape, "moe"), moe)
+        if self.direct:
+            out += (HF.head_forward(self, ori, "bottleneck", "classifier", True, tape, "ori"), ori)
+        else:
+            for i, s in enumerate("rnt"):
+                gi = ori[:, i * C:(i + 1) * C].contiguous()
+                out += (HF.head_forward(self, gi, "bottleneck_" + s, "classifier_" + s, True, tape, s), gi)
+        if moe is not None:
+            out += (0,)                                                  # reg_weight(0) * loss(0)  (AttnMOE.py:118-120)
+        self._nbt_flat += 1                                              # every BatchNorm saw one more batch
+        return out
+
+
+__factory_T_type = {'vit_base_patch16_224': vit_base_patch16_224, 'deit_base_patch16_224': vit_base_patch16_224}
+
+
+def make_model(cfg, num_class, camera_num, view_num=0):
+    """modeling/make_model.py:1223-1237.  'DeMo' and 'DeMoBeiyong' build the PIFE(+HDM+ATMoE) model; the 9-head
+    'DeMo_Parallel' ablation class is out of scope."""
+    arch = cfg.MODEL.get('ARCH', 'DeMo') if hasattr(cfg.MODEL, 'ARCH') else 'DeMo'
+    if arch == 'DeMo_Parallel':
+        raise NotImplementedError("MODEL.ARCH=DeMo_Parallel (SDTPS/DGAF ablation heads) is outside the PIFE->HDM->ATMoE hot path")
+    model = DeMo(num_class, cfg, camera_num, view_num, __factory_T_type)
+    print('===========Building DeMo===========')
+    return model

@@ -1,0 +1,325 @@
+"""Thin Python launchers over the C ABI (include/demo_hip.h).  PyTorch is used only for device
+memory and streams: every function here hands raw device pointers + the current HIP stream to
+libdemo_hip.so.  Tensors must live on a HIP device; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_QUICKGELU, BF16, F32, GemmDesc, check
+
+Tensor = torch.Tensor
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dt_code(t: torch.dtype) -> int:
+    try:
+        return _DT[t]
+    except KeyError:
+        raise TypeError(f"demo2_amd supports float32/bfloat16 tensors, got {t}")
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.DemoHipError("demo2_amd ops need HIP device tensors (no CPU fallback)")
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+def gemm_raw(A: Tensor, B: Tensor, Cout: Tensor, M: int, N: int, K: int, a_rs: int, a_cs: int, b_rs: int, b_cs: int,
+             c_rs: int, *, a_off: int = 0, b_off: int = 0, c_off: int = 0, bias: Optional[Tensor] = None, bias_off: int = 0,
+             residual: Optional[Tensor] = None, act: int = ACT_NONE, alpha: float = 1.0, batch1: int = 1, batch2: int = 1,
+             sA=(0, 0), sB=(0, 0), sC=(0, 0), sBias=(0, 0), act_grad_pre: Optional[Tensor] = None, act_grad_kind: int = 0,
+             accumulate: bool = False, pre_out: Optional[Tensor] = None):
+    """Fully explicit descriptor launch; offsets are in elements of the respective tensor."""
+    _req_cuda(A, B, Cout, bias, residual, act_grad_pre)
+    d = GemmDesc()
+    d.A = A.data_ptr() + a_off * A.element_size()
+    d.B = B.data_ptr() + b_off * B.element_size()
+    d.C = Cout.data_ptr() + c_off * Cout.element_size()
+    d.bias = None if bias is None else bias.data_ptr() + bias_off * 4
+    if bias is not None and bias.dtype != torch.float32:
+        raise TypeError("bias must be fp32")
+    if residual is not None:
+        if residual.dtype != torch.float32:
+            raise TypeError("residual must be fp32")
+        d.residual = residual.data_ptr() + c_off * 4
+    else:
+        d.residual = None
+    d.M, d.N, d.K = M, N, K
+    d.a_rs, d.a_cs, d.b_rs, d.b_cs, d.c_rs = a_rs, a_cs, b_rs, b_cs, c_rs
+    d.dtA, d.dtB, d.dtC = dt_code(A.dtype), dt_code(B.dtype), dt_code(Cout.dtype)
+    d.act, d.alpha = act, alpha
+    d.batch1, d.batch2 = batch1, batch2
+    d.sA1, d.sA2 = sA
+    d.sB1, d.sB2 = sB
+    d.sC1, d.sC2 = sC
+    d.sBias1, d.sBias2 = sBias
+    if act_grad_pre is not None:
+        d.act_grad_pre = act_grad_pre.data_ptr() + c_off * act_grad_pre.element_size()
+        d.dtPre = dt_code(act_grad_pre.dtype)
+        d.act_grad_kind = act_grad_kind
+    else:
+        d.act_grad_pre = None
+        d.dtPre = 0
+        d.act_grad_kind = 0
+    d.accumulate = 1 if accumulate else 0
+    if pre_out is not None:
+        if pre_out.dtype != Cout.dtype:
+            raise TypeError("pre_out must have the dtype of C")
+        d.pre_out = pre_out.data_ptr() + c_off * pre_out.element_size()
+    else:
+        d.pre_out = None
+    check(_lib.load().demo_gemm(C.byref(d), _stream()), "demo_gemm")
+    return Cout
+
+
+def gemm(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+         bias: Optional[Tensor] = None, residual: Optional[Tensor] = None, act: int = ACT_NONE, alpha: float = 1.0,
+         act_grad_pre: Optional[Tensor] = None, act_grad_kind: int = 0, accumulate: bool = False,
+         pre_out: Optional[Tensor] = None, pre_out_new: bool = False):
+    """out[M,N] = act(alpha * a[M,K] @ b[N,K]^T + bias) (* act'(pre)) (+ residual).  a, b may be any 2-D strided views."""
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1], (a.shape, b.shape)
+    M, K = a.shape
+    N = b.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=out_dtype or a.dtype)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    if residual is not None:
+        assert residual.shape == (M, N) and residual.stride() == out.stride()
+    if act_grad_pre is not None:
+        assert act_grad_pre.shape == (M, N) and act_grad_pre.stride() == out.stride()
+    if pre_out_new:
+        pre_out = torch.empty_like(out)
+    if pre_out is not None:
+        assert pre_out.shape == (M, N) and pre_out.stride() == out.stride()
+    gemm_raw(a, b, out, M, N, K, a.stride(0), a.stride(1), b.stride(0), b.stride(1), out.stride(0), bias=bias,
+             residual=residual, act=act, alpha=alpha, act_grad_pre=act_grad_pre, act_grad_kind=act_grad_kind,
+             accumulate=accumulate, pre_out=pre_out)
+    return (out, pre_out) if pre_out_new else out
+
+
+# ------------------------------------------------------------------------------------------------
+# elementwise / layout
+# ------------------------------------------------------------------------------------------------
+def cast_f32_bf16(src: Tensor, dst: Tensor):
+    _req_cuda(src, dst)
+    assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
+    assert src.is_contiguous() and dst.is_contiguous()
+    check(_lib.load().demo_cast_f32_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "demo_cast_f32_bf16")
+    return dst
+
+
+def cast_bf16_f32(src: Tensor, dst: Tensor):
+    _req_cuda(src, dst)
+    assert src.dtype == torch.bfloat16 and dst.dtype == torch.float32 and src.numel() == dst.numel()
+    check(_lib.load().demo_cast_bf16_f32(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "demo_cast_bf16_f32")
+    return dst
+
+
+def transpose(src: Tensor, dst: Optional[Tensor] = None) -> Tensor:
+    _req_cuda(src)
+    assert src.dim() == 2 and src.is_contiguous()
+    r, c = src.shape
+    if dst is None:
+        dst = torch.empty(c, r, device=src.device, dtype=src.dtype)
+    check(_lib.load().demo_transpose(src.data_ptr(), dst.data_ptr(), r, c, dt_code(src.dtype), _stream()), "demo_transpose")
+    return dst
+
+
+def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    _req_cuda(x)
+    assert x.dim() == 2 and x.stride(1) == 1
+    M, N = x.shape
+    if out is None:
+        out = torch.empty(N, device=x.device, dtype=torch.float32)
+        accumulate = False
+    check(_lib.load().demo_colsum(x.data_ptr(), out.data_ptr(), M, N, x.stride(0), dt_code(x.dtype), int(accumulate), _stream()),
+          "demo_colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# patch embedding / tokens
+# ------------------------------------------------------------------------------------------------
+def im2col(img: Tensor, patch: int, stride: int, dtype: torch.dtype) -> Tensor:
+    _req_cuda(img)
+    assert img.dtype == torch.float32 and img.is_contiguous() and img.dim() == 4 and img.shape[1] == 3
+    Bn, _, H, W = img.shape
+    ny, nx = (H - patch) // stride + 1, (W - patch) // stride + 1
+    cols = torch.empty(Bn * ny * nx, 3 * patch * patch, device=img.device, dtype=dtype)
+    check(_lib.load().demo_im2col(img.data_ptr(), cols.data_ptr(), Bn, H, W, patch, stride, dt_code(dtype), _stream()), "demo_im2col")
+    return cols
+
+
+def im2col_into(img: Tensor, cols: Tensor, patch: int, stride: int) -> Tensor:
+    _req_cuda(img, cols)
+    assert img.dtype == torch.float32 and img.is_contiguous() and img.dim() == 4 and img.shape[1] == 3
+    Bn, _, H, W = img.shape
+    ny, nx = (H - patch) // stride + 1, (W - patch) // stride + 1
+    assert cols.is_contiguous() and cols.shape == (Bn * ny * nx, 3 * patch * patch)
+    check(_lib.load().demo_im2col(img.data_ptr(), cols.data_ptr(), Bn, H, W, patch, stride, dt_code(cols.dtype), _stream()), "demo_im2col")
+    return cols
+
+
+def embed_tokens(patch_out: Tensor, cls: Tensor, pos: Tensor, cam_embed: Optional[Tensor], cam: Optional[Tensor],
+                 cam_scale: float, cam_all_tokens: bool, ln_w: Optional[Tensor], ln_b: Optional[Tensor], eps: float,
+                 Bn: int, n_patch: int, save: bool = False):
+    """-> x (Bn*(n_patch+1), W) fp32 [, pre, mean, rstd when save]"""
+    _req_cuda(patch_out, cls, pos)
+    W = patch_out.shape[1]
+    rows = Bn * (n_patch + 1)
+    x = torch.empty(rows, W, device=patch_out.device, dtype=torch.float32)
+    pre = mean = rstd = None
+    if save:
+        pre = torch.empty_like(x)
+        if ln_w is not None:
+            mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+            rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    if cam is not None:
+        assert cam.dtype == torch.int64 and cam.numel() == Bn
+    check(_lib.load().demo_embed_tokens(patch_out.data_ptr(), dt_code(patch_out.dtype), cls.data_ptr(), pos.data_ptr(),
+                                        _ptr(cam_embed), _ptr(cam), float(cam_scale), int(cam_all_tokens), _ptr(ln_w), _ptr(ln_b),
+                                        float(eps), x.data_ptr(), _ptr(pre), _ptr(mean), _ptr(rstd), Bn, n_patch, W, _stream()),
+          "demo_embed_tokens")
+    return (x, pre, mean, rstd) if save else x
+
+
+# ------------------------------------------------------------------------------------------------
+# normalisation
+# ------------------------------------------------------------------------------------------------
+def layernorm_fwd(x: Tensor, w: Tensor, b: Tensor, eps: float, out_dtype: torch.dtype, save: bool = False,
+                  out: Optional[Tensor] = None):
+    _req_cuda(x, w, b)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+    M, D = x.shape
+    y = out if out is not None else torch.empty(M, D, device=x.device, dtype=out_dtype)
+    assert y.is_contiguous() and y.shape == (M, D) and y.dtype == out_dtype
+    mean = rstd = None
+    if save:
+        mean = torch.empty(M, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    check(_lib.load().demo_layernorm_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), float(eps), y.data_ptr(), dt_code(out_dtype),
+                                         _ptr(mean), _ptr(rstd), M, D, _stream()), "demo_layernorm_fwd")
+    return (y, mean, rstd) if save else y
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, dx: Optional[Tensor] = None,
+                  accumulate_dx: bool = False, dw: Optional[Tensor] = None, db: Optional[Tensor] = None):
+    """dx (fp32); dw/db are ACCUMULATED into the given fp32 buffers (zero them first if needed)."""
+    _req_cuda(dy, x)
+    M, D = x.shape
+    if dx is None:
+        dx = torch.empty_like(x)
+        accumulate_dx = False
+    check(_lib.load().demo_layernorm_bwd(dy.data_ptr(), dt_code(dy.dtype), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                         dx.data_ptr(), int(accumulate_dx), _ptr(dw), _ptr(db), M, D, _stream()), "demo_layernorm_bwd")
+    return dx
+
+
+def batchnorm_fwd(x: Tensor, w: Tensor, b: Tensor, running_mean: Tensor, running_var: Tensor, training: bool, momentum: float,
+                  eps: float, out_dtype: torch.dtype = torch.float32, save: bool = False, group=None, gate: Optional[Tensor] = None):
+    """group = (gsz, n_inner, n_outer, pstride, sstride) for the grouped-parameter form (see header)."""
+    _req_cuda(x, w, b, running_mean, running_var)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+    Bn, Fd = x.shape
+    y = torch.empty(Bn, Fd, device=x.device, dtype=out_dtype)
+    sm = si = None
+    if save and training:
+        sm = torch.empty(Fd, device=x.device, dtype=torch.float32)
+        si = torch.empty(Fd, device=x.device, dtype=torch.float32)
+    gsz, ni, no, ps, ss = group if group is not None else (0, 1, 1, 0, 0)
+    check(_lib.load().demo_batchnorm_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
+                                         int(training), float(momentum), float(eps), y.data_ptr(), dt_code(out_dtype), _ptr(sm), _ptr(si),
+                                         Bn, Fd, gsz, ni, no, ps, ss, _ptr(gate), _stream()), "demo_batchnorm_fwd")
+    return (y, sm, si) if save else y
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def attention_fwd(qkv: Tensor, Bn: int, L: int, H: int, save_lse: bool = False):
+    _req_cuda(qkv)
+    D = H * 64
+    assert qkv.shape == (Bn * L, 3 * D) and qkv.is_contiguous()
+    out = torch.empty(Bn * L, D, device=qkv.device, dtype=qkv.dtype)
+    lse = torch.empty(Bn * H * L, device=qkv.device, dtype=torch.float32) if save_lse else None
+    check(_lib.load().demo_attention_fwd(qkv.data_ptr(), out.data_ptr(), _ptr(lse), Bn, L, H, 64, dt_code(qkv.dtype), _stream()),
+          "demo_attention_fwd")
+    return (out, lse) if save_lse else out
+
+
+# ------------------------------------------------------------------------------------------------
+# PIFE / HDM / ATMoE pieces
+# ------------------------------------------------------------------------------------------------
+def pife_pool_cat(tokens: Tensor, Bn: int, L: int) -> Tensor:
+    _req_cuda(tokens)
+    Cd = tokens.shape[-1]
+    assert tokens.is_contiguous() and tokens.numel() == Bn * L * Cd
+    z = torch.empty(Bn, 2 * Cd, device=tokens.device, dtype=torch.float32)
+    check(_lib.load().demo_pife_pool_cat(tokens.data_ptr(), dt_code(tokens.dtype), z.data_ptr(), Bn, L, Cd, _stream()), "demo_pife_pool_cat")
+    return z
+
+
+def set_token0(tokens: Tensor, glob: Tensor, glob_off: int, glob_ld: int, Bn: int, L: int):
+    """tokens[b,0,:] = glob_flat[glob_off + b*glob_ld : ... + C]"""
+    _req_cuda(tokens, glob)
+    Cd = tokens.shape[-1]
+    assert glob.dtype == torch.float32 and tokens.is_contiguous() and tokens.numel() == Bn * L * Cd
+    check(_lib.load().demo_set_token0(tokens.data_ptr(), dt_code(tokens.dtype), glob.data_ptr() + 4 * glob_off, glob_ld, Bn, L, Cd, _stream()),
+          "demo_set_token0")
+    return tokens
+
+
+def get_token0(tokens: Tensor, out: Tensor, out_off: int, out_ld: int, Bn: int, L: int):
+    """out_flat[out_off + b*out_ld : ... + C] = tokens[b,0,:] (fp32)"""
+    _req_cuda(tokens, out)
+    Cd = tokens.shape[-1]
+    assert out.dtype == torch.float32 and tokens.is_contiguous() and tokens.numel() == Bn * L * Cd
+    check(_lib.load().demo_get_token0(tokens.data_ptr(), dt_code(tokens.dtype), out.data_ptr() + 4 * out_off, out_ld, Bn, L, Cd, _stream()),
+          "demo_get_token0")
+    return out
+
+
+def hdm_softmax_pool(S: Tensor, tokens: Tensor, Bs: int, L: int, Cd: int, Hh: int, ldS: int, p_drop: float = 0.0, seed: int = 0,
+                     save_probs: bool = False):
+    _req_cuda(S, tokens)
+    assert S.dtype == torch.float32 and S.shape == (3 * Bs * L, ldS) and S.is_contiguous() and ldS >= 7 * Hh
+    assert tokens.is_contiguous() and tokens.numel() == 3 * Bs * L * Cd
+    pooled = torch.empty(Bs, 7, Hh, Cd, device=S.device, dtype=torch.float32)
+    psum = torch.empty(Bs, 7, Hh, device=S.device, dtype=torch.float32)
+    probs = torch.empty(Bs, 7, Hh, 3 * L, device=S.device, dtype=torch.float32) if save_probs else None
+    check(_lib.load().demo_hdm_softmax_pool(S.data_ptr(), ldS, tokens.data_ptr(), dt_code(tokens.dtype), pooled.data_ptr(), psum.data_ptr(),
+                                            _ptr(probs), Bs, L, Cd, Hh, float(p_drop), int(seed) & (2 ** 64 - 1), _stream()),
+          "demo_hdm_softmax_pool")
+    return pooled, psum, probs
+
+
+def hdm_vbias(y: Tensor, bias_base: Tensor, bias_off: int, bias_stride: int, psum: Tensor, Bs: int, Cd: int, Hh: int):
+    _req_cuda(y, bias_base, psum)
+    check(_lib.load().demo_hdm_vbias(y.data_ptr(), bias_base.data_ptr() + 4 * bias_off, bias_stride, psum.data_ptr(), Bs, Cd, Hh, _stream()),
+          "demo_hdm_vbias")
+    return y
+
+
+def atmoe_gate_softmax(q: Tensor, k: Tensor, Bs: int, Cd: int, H: int) -> Tensor:
+    _req_cuda(q, k)
+    assert q.dtype == torch.float32 and k.dtype == torch.float32 and q.is_contiguous() and k.is_contiguous()
+    gates = torch.empty(Bs, H, 7, device=q.device, dtype=torch.float32)
+    check(_lib.load().demo_atmoe_gate_softmax(q.data_ptr(), k.data_ptr(), gates.data_ptr(), Bs, Cd, H, _stream()), "demo_atmoe_gate_softmax")
+    return gates

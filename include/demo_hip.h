@@ -1,0 +1,151 @@
+/*
+ * demo_hip.h -- C ABI of libdemo_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for
+ * the DeMo PIFE -> HDM -> ATMoE hot path.
+ *
+ * The reference (maxingan2412/DeMo2) is pure Python/PyTorch and has no FFI of its own; each
+ * entry point below replaces the PyTorch ops of the cited reference lines (paths relative to
+ * the reference root).  The library never allocates or frees device memory, keeps no mutable
+ * global state, launches asynchronously on the caller's stream and is re-entrant (forward runs
+ * on the Python main thread, backward on PyTorch's autograd thread).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless said otherwise; sizes are element counts;
+ *   - `stream` is a hipStream_t passed as void*;
+ *   - dtype codes: DEMO_F32 = 0, DEMO_BF16 = 1.  "T" below = the compute/activation dtype;
+ *   - return value 0 = launched; negative = argument/launch error, text via demo_last_error().
+ */
+#ifndef DEMO_HIP_H
+#define DEMO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEMO_F32 0
+#define DEMO_BF16 1
+
+#define DEMO_ACT_NONE 0
+#define DEMO_ACT_QUICKGELU 1 /* x*sigmoid(1.702x): modeling/clip/model.py:163-165, modeling/moe/AttnMOE.py:5-7 */
+#define DEMO_ACT_GELU 2      /* erf GELU: modeling/backbones/vit_pytorch.py:126 (nn.GELU) */
+
+int demo_abi_version(void);
+const char* demo_last_error(void); /* thread-local, host pointer */
+
+/* ---- GEMM --------------------------------------------------------------------------------
+ * C[z][m,n] = act( alpha * sum_k A[z][m,k] * B[z][n,k] + bias[z][n] ) (+ residual[z][m,n])
+ * Replaces every nn.Linear / F.linear / `@` on the path (e.g. clip/model.py:172-178,225,484;
+ * vit_pytorch.py:159-170,132-140; AttnMOE.py:27-31,53-58; make_model.py:52-58,134-138).
+ * A[m,k] lives at A + m*a_rs + k*a_cs (elements), B[n,k] at B + n*b_rs + k*b_cs, so every
+ * transposition needed by forward and backward is a choice of strides.  Two-level batching
+ * z = z1*batch2 + z2 with independent strides serves the per-head / per-branch grouped
+ * products of HDM and ATMoE.  bf16 x bf16 with K-contiguous operands takes the MFMA
+ * (v_mfma_f32_16x16x32_bf16) LDS-tiled kernel; everything else a generic fp32-accumulate kernel. */
+typedef struct demo_gemm_desc {
+  const void* A;
+  const void* B;
+  void* C;
+  const float* bias;      /* [N] fp32 or NULL */
+  const float* residual;  /* fp32, indexed like C (same ldc / batch strides), or NULL */
+  int32_t M, N, K;
+  int64_t a_rs, a_cs, b_rs, b_cs, c_rs;
+  int32_t dtA, dtB, dtC;
+  int32_t act;
+  float alpha;
+  int32_t batch1, batch2; /* >=1 */
+  int64_t sA1, sA2, sB1, sB2, sC1, sC2, sBias1, sBias2;
+  /* optional backward epilogue: C *= act'(pre[m,n]) where pre is indexed like C (dtype dtPre);
+     used for d(fc1 pre-activation) = (dY W2) * act'(pre)  */
+  const void* act_grad_pre;
+  int32_t dtPre;
+  int32_t act_grad_kind;  /* DEMO_ACT_* whose derivative is applied */
+  int32_t accumulate;     /* 1: C += result (fp32 C only) */
+  void* pre_out;          /* optional: value BEFORE `act` (after alpha, bias), indexed and typed like C; saved for backward */
+} demo_gemm_desc;
+int demo_gemm(const demo_gemm_desc* d, void* stream);
+int demo_gemm_desc_size(void); /* sizeof(demo_gemm_desc): lets a foreign binding verify its struct layout */
+
+/* ---- elementwise / layout ----------------------------------------------------------------- */
+/* fp32 -> bf16 shadow copy of the flat parameter buffer (one launch per optimizer step). */
+int demo_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+int demo_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream);
+/* 2-D transpose with dtype preserved: dst[c, r] = src[r, c]; used for weight^T shadows (backward). */
+int demo_transpose(const void* src, void* dst, int32_t rows, int32_t cols, int32_t dt, void* stream);
+/* column sums: out[n] (+)= sum_m X[m, n]   (bias gradients) */
+int demo_colsum(const void* X, float* out, int32_t M, int32_t N, int64_t ldx, int32_t dt, int32_t accumulate, void* stream);
+
+/* ---- patch embedding ---------------------------------------------------------------------- */
+/* im2col for the patch-embed conv (clip/model.py:432,447-449; vit_pytorch.py:303,321-323):
+ * img fp32 (Bn,3,H,W) -> cols T (Bn*ny*nx, 3*p*p), column order (c,ky,kx) = conv weight order. */
+int demo_im2col(const float* img, void* cols, int32_t Bn, int32_t H, int32_t W, int32_t patch, int32_t stride,
+                int32_t dt, void* stream);
+/* adjoint of demo_im2col is not needed (images carry no gradient). */
+
+/* token assembly + optional pre-LayerNorm (clip/model.py:450-457; vit_pytorch.py:419-431):
+ * x[b,0,:] = cls + pos[0] + cam_scale*cam_embed[cam[b]] ; x[b,1+i,:] = patch[b,i,:] + pos[1+i]
+ *            (+ cam_scale*cam_embed[cam[b]] on every token when cam_all_tokens, the ViT SIE rule);
+ * if ln_w != NULL: x = LayerNorm(x; ln_w, ln_b, eps).  x is the fp32 residual stream (Bn*(1+np), W).
+ * pre (optional, fp32) receives the un-normalised sum for the backward pass. */
+int demo_embed_tokens(const void* patch, int32_t dt_patch, const float* cls, const float* pos,
+                      const float* cam_embed, const int64_t* cam, float cam_scale, int32_t cam_all_tokens,
+                      const float* ln_w, const float* ln_b, float eps, float* x, float* pre, float* mean, float* rstd,
+                      int32_t Bn, int32_t np, int32_t W, void* stream);
+
+/* ---- normalisation ------------------------------------------------------------------------ */
+/* LayerNorm over the last dim of fp32 x (M, D) -> y (dtype dtY); optional mean/rstd (M) saved for backward.
+ * (clip/model.py:154-160; nn.LayerNorm in vit_pytorch.py:178,182,401; make_model.py:52) */
+int demo_layernorm_fwd(const float* x, const float* w, const float* b, float eps, void* y, int32_t dtY,
+                       float* mean, float* rstd, int32_t M, int32_t D, void* stream);
+/* dx (fp32, optionally accumulated into) from dy (dtype dtDy); dw/db partial sums are reduced inside. */
+int demo_layernorm_bwd(const void* dy, int32_t dtDy, const float* x, const float* w, const float* mean, const float* rstd,
+                       float* dx, int32_t accumulate_dx, float* dw, float* db, int32_t M, int32_t D, void* stream);
+
+/* BatchNorm1d over x (Bn, F) fp32 (nn.BatchNorm1d at AttnMOE.py:30,53; make_model.py:136,176).
+ * training!=0: batch statistics (biased var), running stats updated in place with `momentum`
+ * (unbiased var), save_mean/save_invstd (F) written.  Otherwise running stats are used.
+ * Grouped parameters (the 7*H expert BNs of ATMoE live in one call): feature f belongs to group
+ * g = f / gsz; its parameters are at base + pblock(g)*pstride + f%gsz where
+ * pblock(g) = (g % n_inner)*n_outer + g / n_inner (expert (h,j) block order); gsz = 0 -> plain.
+ * gate (optional, (Bn, n_inner, n_outer) fp32): y *= gate[b, g % n_inner, g / n_inner]  (AttnMOE.py:46). */
+int demo_batchnorm_fwd(const float* x, const float* w, const float* b, float* running_mean, float* running_var,
+                       int32_t training, float momentum, float eps, void* y, int32_t dtY, float* save_mean,
+                       float* save_invstd, int32_t Bn, int32_t F, int32_t gsz, int32_t n_inner, int32_t n_outer,
+                       int64_t pstride, int64_t sstride, const float* gate, void* stream);
+
+/* ---- ViT self-attention (L <= 144 tokens, head dim 64) ------------------------------------- */
+/* qkv T (Bn*L, 3*D) packed [q | k | v], heads contiguous inside each third
+ * (nn.MultiheadAttention packed in-proj, clip/model.py:172,225; vit_pytorch.py:159-167).
+ * out T (Bn*L, D) = softmax(q k^T / sqrt(dh)) v per (image, head); lse (Bn*H*L) fp32 optional. */
+int demo_attention_fwd(const void* qkv, void* out, float* lse, int32_t Bn, int32_t L, int32_t H, int32_t dh,
+                       int32_t dt, void* stream);
+
+/* ---- PIFE ----------------------------------------------------------------------------------- */
+/* z[b] = cat[ tokens[b,0,:], mean_i tokens[b,1+i,:] ] -> fp32 (Bn, 2C)  (make_model.py:301-303). */
+int demo_pife_pool_cat(const void* tokens, int32_t dt, float* z, int32_t Bn, int32_t L, int32_t C, void* stream);
+/* tokens[b,0,:] = glob[b,:] : the reduced global replaces the cls row of the HDM key/value stream
+ * (AttnMOE.py:155-165). */
+int demo_set_token0(void* tokens, int32_t dt, const float* glob, int64_t glob_ld, int32_t Bn, int32_t L, int32_t C, void* stream);
+/* out[b, 0:C] = tokens[b,0,:] as fp32 (row stride out_ld): the cls rows when GLOBAL_LOCAL is off (make_model.py:370). */
+int demo_get_token0(const void* tokens, int32_t dt, float* out, int64_t out_ld, int32_t Bn, int32_t L, int32_t C, void* stream);
+
+/* ---- HDM (AttnMOE.py:153-191), folded single-query form ------------------------------------- */
+/* scores S (3*Bs*L, ldS) fp32, column br*Hh + h = score of branch br / head h for that token (all 7 branches are
+ * scored for every modality; only the attended ones are read), come from demo_gemm against the folded keys.  This kernel: for sample b, branch br (0..6 = r,n,t,rn,rt,nt,rnt)
+ * and head h: softmax over the concatenated streams of that branch, optional dropout (seed/offset
+ * counter RNG, p_drop), pooled[b,br,h,:] = sum_l p_l * tokens_l  -> fp32 (Bs,7,Hh,C);
+ * psum[b,br,h] = sum_l p_l (== 1 without dropout); probs (optional) saved for backward. */
+int demo_hdm_softmax_pool(const float* S, int64_t ldS, const void* tokens, int32_t dt, float* pooled, float* psum, float* probs,
+                          int32_t Bs, int32_t L, int32_t C, int32_t Hh, float p_drop, uint64_t seed, void* stream);
+/* y[b, br, h*dh + e] += bias[br][h*dh+e] * psum[b,br,h]   (value-projection bias under dropout) */
+int demo_hdm_vbias(float* y, const float* bias, int64_t bias_stride, const float* psum, int32_t Bs, int32_t C, int32_t Hh,
+                   void* stream);
+
+/* ---- ATMoE gate (AttnMOE.py:61-68) ----------------------------------------------------------- */
+/* gates[b,h,j] = softmax_j( q[b, h*d:(h+1)*d] . k[b, j, h*d:(h+1)*d] * d^-0.5 ) */
+int demo_atmoe_gate_softmax(const float* q, const float* k, float* gates, int32_t Bs, int32_t C, int32_t H, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEMO_HIP_H */

@@ -1,0 +1,142 @@
+"""GPU: the whole hot path (make_model(...).forward through the C ABI) against the CPU oracle on the same
+seeded weights and inputs.
+
+fp32 compute mode: tolerance 2e-4 -- "within fp32 tolerance" of the north star (identical algorithm, different
+summation order).  bf16 compute mode (the benchmarked mode; the reference trains under fp16 autocast): features
+are O(1) after BatchNorm/LayerNorm, tolerance 6e-2 absolute on bf16-rounded activations through 12 blocks;
+mAP on a synthetic gallery must agree within 0.1 points (north star).
+"""
+import numpy as np
+import pytest
+import torch
+
+from demo2_amd.modeling import make_model
+from oracle import demo_oracle as O
+from util import cpu_sd, make_cfg, small_cfg, spec_of, synth_batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def build(cfg, classes, cams, seed=0, dtype=torch.float32):
+    torch.manual_seed(seed)
+    m = make_model(cfg, classes, cams, 0)
+    sd = O.init_state_dict(spec_of(m), seed=seed + 1)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval().set_compute_dtype(dtype)
+    return m, sd
+
+
+@pytest.mark.parametrize("arch", ["clip", "vit"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
+def test_small_eval_all_patterns(arch, dtype, tol):
+    m, sd = build(small_cfg(arch), 11, 3, dtype=dtype)
+    spec = spec_of(m)
+    x, cam = synth_batch(4, 64, 32, 3)
+    xd = {k: v.to(DEV) for k, v in x.items()}
+    for rp in (1, 2, 3):
+        want = O.model_forward(sd, spec, x, cam, return_pattern=rp)
+        with torch.no_grad():
+            got = m(xd, cam_label=cam.to(DEV), return_pattern=rp)
+        assert got.shape == want.shape and got.dtype == torch.float32
+        torch.testing.assert_close(got.cpu(), want, rtol=tol, atol=tol)
+    # cam_label inside the dict overrides the keyword (make_model.py:241-242)
+    xd2 = dict(xd, cam_label=cam.to(DEV))
+    with torch.no_grad():
+        got = m(xd2, cam_label=torch.zeros_like(cam).to(DEV), return_pattern=3)
+    torch.testing.assert_close(got.cpu(), O.model_forward(sd, spec, x, cam, return_pattern=3), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("miss", ["r", "n", "t", "rn", "rt", "nt", "nothing"])
+def test_missing_modality(miss):
+    m, sd = build(small_cfg("clip", MISS=miss), 11, 3)
+    spec = spec_of(m)
+    assert spec.miss == miss
+    x, cam = synth_batch(3, 64, 32, 3, seed=5)
+    want = O.model_forward(sd, spec, x, cam, return_pattern=3)
+    with torch.no_grad():
+        got = m({k: v.to(DEV) for k, v in x.items()}, cam_label=cam.to(DEV))
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("kw", [dict(HDM=True, ATM=False), dict(HDM=False, ATM=False), dict(GLOBAL_LOCAL=False), dict(SIE_CAMERA=False),
+                                dict(head=2), dict(direct=0)])
+def test_config_switches(kw):
+    kw = dict(kw)
+    head, direct = kw.pop("head", 4), kw.pop("direct", 1)
+    m, sd = build(small_cfg("clip", head=head, direct=direct, **kw), 11, 3)
+    spec = spec_of(m)
+    x, cam = synth_batch(2, 64, 32, 3, seed=9)
+    want = O.model_forward(sd, spec, x, cam, return_pattern=3)
+    with torch.no_grad():
+        got = m({k: v.to(DEV) for k, v in x.items()}, cam_label=cam.to(DEV))
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-4, atol=2e-4)
+
+
+def test_single_sample_eval():
+    """B=1: the reference squeezes to (C,) and re-expands (AttnMOE.py:95-102,181-189); output stays (1, D)."""
+    m, sd = build(small_cfg("clip"), 11, 3)
+    x, cam = synth_batch(1, 64, 32, 3, seed=2)
+    want = O.model_forward(sd, spec_of(m), x, cam)
+    with torch.no_grad():
+        got = m({k: v.to(DEV) for k, v in x.items()}, cam_label=cam.to(DEV))
+    assert got.shape == (1, 10 * 128)
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("name,classes,cams,size", [("RGBNT201", 171, 4, (256, 128)), ("RGBNT100", 50, 8, (128, 256))])
+def test_full_size_eval_fp32_and_bf16(name, classes, cams, size):
+    """BASELINE configs A and B at full model size (98.8 M parameters), B=2."""
+    cfg = make_cfg(name)
+    m, sd = build(cfg, classes, cams)
+    spec = spec_of(m)
+    x, cam = synth_batch(2, size[0], size[1], cams)
+    want = O.model_forward(sd, spec, x, cam, return_pattern=3)
+    xd = {k: v.to(DEV) for k, v in x.items()}
+    with torch.no_grad():
+        got = m(xd, cam_label=cam.to(DEV))
+    torch.testing.assert_close(got.cpu(), want, rtol=5e-4, atol=5e-4)
+    m.set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        got = m(xd, cam_label=cam.to(DEV))
+    err = (got.cpu() - want).abs()
+    assert err.max() < 0.15 and err.mean() < 0.02, (err.max(), err.mean())
+
+
+def test_vit_b_full_size_eval():
+    """Config V: ImageNet ViT-B trunk (C=768, HEAD=12, SIE on every token)."""
+    cfg = make_cfg("RGBNT201", TRANSFORMER_TYPE="vit_base_patch16_224", HEAD=12, SIE_COE=3.0)
+    m, sd = build(cfg, 171, 6)
+    x, cam = synth_batch(2, 256, 128, 6)
+    want = O.model_forward(sd, spec_of(m), x, cam)
+    with torch.no_grad():
+        got = m({k: v.to(DEV) for k, v in x.items()}, cam_label=cam.to(DEV))
+    torch.testing.assert_close(got.cpu(), want, rtol=5e-4, atol=5e-4)
+
+
+def test_synthetic_map_parity_bf16():
+    """north star: mAP / Rank-1 on a synthetic eval set within +-0.1 of the fp32 CPU path (bf16 HIP features)."""
+    cfg = make_cfg("RGBNT201")
+    m, sd = build(cfg, 171, 4, dtype=torch.bfloat16)
+    spec = spec_of(m)
+    rng = np.random.RandomState(0)
+    ids, per = 8, 4
+    g = torch.Generator().manual_seed(7)
+    protos = {k: torch.randn(ids, 3, 256, 128, generator=g) for k in ("RGB", "NI", "TI")}
+    pid = np.repeat(np.arange(ids), per)
+    camid = np.tile(np.arange(per) % 2, ids)
+    x = {k: protos[k][pid] + 0.8 * torch.randn(ids * per, 3, 256, 128, generator=g) for k in protos}
+    cam = torch.tensor(camid)
+    order = rng.permutation(ids * per)
+    x = {k: v[order] for k, v in x.items()}
+    pid, camid, cam = pid[order], camid[order], cam[order]
+    feats_ref, feats_hip = [], []
+    for i in range(0, ids * per, 8):
+        xb = {k: v[i:i + 8] for k, v in x.items()}
+        feats_ref.append(O.model_forward(sd, spec, xb, cam[i:i + 8]))
+        with torch.no_grad():
+            feats_hip.append(m({k: v.to(DEV) for k, v in xb.items()}, cam_label=cam[i:i + 8].to(DEV)).cpu())
+    nq = 12
+    cmc_r, map_r = O.r1_map(torch.cat(feats_ref), pid, camid, nq)
+    cmc_h, map_h = O.r1_map(torch.cat(feats_hip), pid, camid, nq)
+    assert abs(map_r - map_h) * 100 <= 0.1 and abs(cmc_r[0] - cmc_h[0]) * 100 <= 0.1, (map_r, map_h, cmc_r[0], cmc_h[0])

@@ -1,0 +1,309 @@
+"""GPU: every C-ABI entry point against a CPU fp32 computation of the same op (torch on CPU / the oracle).
+fp32 paths: tolerance = fp32 re-association noise.  bf16 paths: inputs are rounded to bf16 first, products are
+accumulated in fp32 by the MFMA, so the tolerance is the bf16 OUTPUT rounding (2^-8 relative)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from demo2_amd import ops
+from demo2_amd._lib import ACT_GELU, ACT_NONE, ACT_QUICKGELU
+from oracle import demo_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+def act_ref(x, act):
+    if act == ACT_QUICKGELU:
+        return O.quick_gelu(x)
+    if act == ACT_GELU:
+        return F.gelu(x)
+    return x
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(37, 171, 100), (1, 512, 64), (129, 64, 17), (300, 256, 192)])
+@pytest.mark.parametrize("act", [ACT_NONE, ACT_QUICKGELU, ACT_GELU])
+def test_gemm_generic_fp32(M, N, K, act):
+    a, b, bias, res = rnd(M, K), rnd(N, K, seed=1), rnd(N, seed=2), rnd(M, N, seed=3)
+    want = act_ref(0.5 * a @ b.t() + bias, act) + res
+    got = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), residual=res.to(DEV), act=act, alpha=0.5)
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-4, atol=1e-4)
+
+
+def test_gemm_generic_strides_batches_and_epilogues():
+    # transposed operands through strides
+    a, b = rnd(50, 70), rnd(70, 33, seed=1)          # want a @ b  -> B[n,k] = b[k,n]
+    got = ops.gemm(a.to(DEV), b.to(DEV).t())
+    torch.testing.assert_close(got.cpu(), a @ b, rtol=1e-4, atol=1e-4)
+    at = rnd(70, 50, seed=2)                          # A given as (K, M)
+    got = ops.gemm(at.to(DEV).t(), b.to(DEV).t())
+    torch.testing.assert_close(got.cpu(), at.t() @ b, rtol=1e-4, atol=1e-4)
+    # two-level batching with bias: C[z1,z2] = A[z1,z2] @ B[z1,z2]^T + bias[z1,z2]
+    Z1, Z2, M, N, K = 3, 4, 5, 6, 7
+    A, B, bias = rnd(Z1, Z2, M, K), rnd(Z1, Z2, N, K, seed=1), rnd(Z1, Z2, N, seed=2)
+    Cd = torch.empty(Z1, Z2, M, N, device=DEV)
+    ops.gemm_raw(A.to(DEV), B.to(DEV), Cd, M, N, K, K, 1, K, 1, N, bias=bias.to(DEV), batch1=Z1, batch2=Z2,
+                 sA=(Z2 * M * K, M * K), sB=(Z2 * N * K, N * K), sC=(Z2 * M * N, M * N), sBias=(Z2 * N, N))
+    torch.testing.assert_close(Cd.cpu(), A @ B.transpose(-1, -2) + bias[:, :, None, :], rtol=1e-4, atol=1e-4)
+    # pre_out, act-grad epilogue, accumulate
+    a, b, bias = rnd(40, 30), rnd(20, 30, seed=1), rnd(20, seed=2)
+    out, pre = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), act=ACT_QUICKGELU, pre_out_new=True)
+    torch.testing.assert_close(pre.cpu(), a @ b.t() + bias, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(out.cpu(), O.quick_gelu(a @ b.t() + bias), rtol=1e-4, atol=1e-4)
+    for kind in (ACT_QUICKGELU, ACT_GELU):
+        p = rnd(40, 20, seed=5).requires_grad_(True)
+        act_ref(p, kind).sum().backward()
+        got = ops.gemm(a.to(DEV), b.to(DEV), act_grad_pre=p.detach().to(DEV), act_grad_kind=kind)
+        torch.testing.assert_close(got.cpu(), (a @ b.t()) * p.grad, rtol=1e-4, atol=1e-4)
+    acc = rnd(40, 20, seed=9)
+    got = ops.gemm(a.to(DEV), b.to(DEV), out=acc.to(DEV), accumulate=True)
+    torch.testing.assert_close(got.cpu(), acc + a @ b.t(), rtol=1e-4, atol=1e-4)
+    # mixed dtypes: fp32 activations x bf16 weights
+    got = ops.gemm(a.to(DEV), b.to(DEV).bfloat16(), out_dtype=torch.float32)
+    torch.testing.assert_close(got.cpu(), a @ b.bfloat16().float().t(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (128, 128, 64), (1161, 384, 128), (24768 // 8, 2304, 768)])
+def test_gemm_bf16_mfma(M, N, K):
+    a, b, bias, res = rnd(M, K).bfloat16(), rnd(N, K, seed=1, scale=K ** -0.5).bfloat16(), rnd(N, seed=2), rnd(M, N, seed=3)
+    ref = a.float() @ b.float().t()
+    got = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), act=ACT_QUICKGELU)                   # bf16 out
+    assert got.dtype == torch.bfloat16
+    torch.testing.assert_close(got.float().cpu(), O.quick_gelu(ref + bias), rtol=1e-2, atol=1e-2)
+    got, pre = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), residual=res.to(DEV), out_dtype=torch.float32, alpha=2.0,
+                        pre_out_new=True)
+    torch.testing.assert_close(got.cpu(), 2 * ref + bias + res, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(pre.cpu(), 2 * ref + bias, rtol=1e-3, atol=1e-3)
+    # asymmetric-operand check of the fragment maps: A = identity block, B asymmetric integers (exact in bf16)
+    if K == 128 and M >= 128:
+        a2 = torch.zeros(M, K)
+        a2[:K, :K] = torch.eye(K)
+        b2 = (torch.arange(N)[:, None] * 2 + torch.arange(K)[None, :] % 7).float()
+        got = ops.gemm(a2.bfloat16().to(DEV), b2.bfloat16().to(DEV), out_dtype=torch.float32)
+        assert torch.equal(got.cpu(), a2.bfloat16().float() @ b2.bfloat16().float().t())
+
+
+def test_gemm_bf16_batched_and_in_place_residual():
+    Z, M, N, K = 3, 130, 128, 64
+    A, B = rnd(Z, M, K).bfloat16(), rnd(Z, N, K, seed=1).bfloat16()
+    Cd = torch.empty(Z, M, N, device=DEV, dtype=torch.float32)
+    ops.gemm_raw(A.to(DEV), B.to(DEV), Cd, M, N, K, K, 1, K, 1, N, batch1=Z, sA=(M * K, 0), sB=(N * K, 0), sC=(M * N, 0))
+    torch.testing.assert_close(Cd.cpu(), A.float() @ B.float().transpose(-1, -2), rtol=1e-3, atol=1e-3)
+    x = rnd(M, N, seed=4).to(DEV)
+    want = x.cpu() + A[0].float() @ B[0].float().t()
+    ops.gemm(A[0].to(DEV), B[0].to(DEV), residual=x, out=x)
+    torch.testing.assert_close(x.cpu(), want, rtol=1e-3, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("M,D", [(7, 128), (258, 768), (33, 1024), (5, 1536)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_layernorm_fwd(M, D, dt):
+    x, w, b = rnd(M, D, scale=2.0) + 0.5, 1 + rnd(D, seed=1, scale=0.1), rnd(D, seed=2, scale=0.1)
+    want = O.layer_norm(x, w, b, 1e-5)
+    y, mean, rstd = ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, dt, save=True)
+    tol = dict(rtol=1e-5, atol=1e-5) if dt == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(y.float().cpu(), want, **tol)
+    torch.testing.assert_close(mean.cpu(), x.mean(-1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(rstd.cpu(), (x.var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,D", [(300, 768), (9, 128)])
+def test_layernorm_bwd(M, D):
+    x = (rnd(M, D) + 0.3).requires_grad_(True)
+    w, b = (1 + rnd(D, seed=1, scale=0.1)).requires_grad_(True), rnd(D, seed=2, scale=0.1).requires_grad_(True)
+    dy = rnd(M, D, seed=3)
+    O.layer_norm(x, w, b, 1e-5).backward(dy)
+    _, mean, rstd = ops.layernorm_fwd(x.detach().to(DEV), w.detach().to(DEV), b.detach().to(DEV), 1e-5, torch.float32, save=True)
+    dw, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    dx = ops.layernorm_bwd(dy.to(DEV), x.detach().to(DEV), w.detach().to(DEV), mean, rstd, dw=dw, db=db)
+    torch.testing.assert_close(dx.cpu(), x.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-4, atol=1e-4)
+    base = rnd(M, D, seed=7)
+    dx2 = ops.layernorm_bwd(dy.bfloat16().to(DEV), x.detach().to(DEV), w.detach().to(DEV), mean, rstd, dx=base.to(DEV), accumulate_dx=True)
+    torch.testing.assert_close(dx2.cpu(), base + x.grad, rtol=2e-2, atol=2e-2)
+
+
+def test_batchnorm_fwd_plain_and_grouped():
+    Bn, Fd = 16, 96
+    x, w, b = rnd(Bn, Fd) * 2 + 1, 1 + rnd(Fd, seed=1, scale=0.1), rnd(Fd, seed=2, scale=0.1)
+    rm, rv = rnd(Fd, seed=3, scale=0.1), (1 + rnd(Fd, seed=4, scale=0.1)).abs()
+    want = F.batch_norm(x, rm.clone(), rv.clone(), w, b, False, 0.1, 1e-5)
+    got = ops.batchnorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), rm.to(DEV), rv.to(DEV), False, 0.1, 1e-5)
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
+    rm2, rv2 = rm.clone(), rv.clone()
+    want = F.batch_norm(x, rm2, rv2, w, b, True, 0.1, 1e-5)
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    got, sm, si = ops.batchnorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), rmd, rvd, True, 0.1, 1e-5, save=True)
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rmd.cpu(), rm2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rvd.cpu(), rv2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(sm.cpu(), x.mean(0), rtol=1e-5, atol=1e-5)
+    with pytest.raises(Exception):
+        ops.batchnorm_fwd(x[:1].contiguous().to(DEV), w.to(DEV), b.to(DEV), rmd, rvd, True, 0.1, 1e-5)
+    # grouped: feature f = j*C + h*d + k uses parameter block (h*7 + j), gate[b,h,j]
+    H, d, J = 2, 8, 7
+    Cc = H * d
+    x = rnd(Bn, J * Cc) + 0.2
+    pstride, sstride = 3 * d + 5, 2 * d + 3
+    pw, pb = rnd(H * J * pstride, seed=5), rnd(H * J * pstride, seed=6)
+    srm, srv = rnd(H * J * sstride, seed=7, scale=0.1), (1 + rnd(H * J * sstride, seed=8, scale=0.1)).abs()
+    gate = torch.rand(Bn, H, J, generator=torch.Generator().manual_seed(3))
+    want = torch.empty_like(x)
+    for j in range(J):
+        for h in range(H):
+            blk = h * J + j
+            sl = slice(j * Cc + h * d, j * Cc + (h + 1) * d)
+            y = F.batch_norm(x[:, sl], srm[blk * sstride:blk * sstride + d], srv[blk * sstride:blk * sstride + d],
+                             pw[blk * pstride:blk * pstride + d], pb[blk * pstride:blk * pstride + d], False, 0.1, 1e-5)
+            want[:, sl] = y * gate[:, h, j, None]
+    got = ops.batchnorm_fwd(x.to(DEV), pw.to(DEV), pb.to(DEV), srm.to(DEV), srv.to(DEV), False, 0.1, 1e-5,
+                            group=(d, H, J, pstride, sstride), gate=gate.to(DEV))
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attn_ref(qkv, Bn, L, H):
+    D = H * 64
+    q, k, v = qkv.float().reshape(Bn, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    o = s.softmax(-1) @ v
+    return o.transpose(1, 2).reshape(Bn * L, D), torch.logsumexp(s, -1).reshape(-1)
+
+
+@pytest.mark.parametrize("Bn,L,H", [(3, 129, 12), (2, 9, 2), (1, 144, 3), (2, 17, 1)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_attention_fwd(Bn, L, H, dt):
+    qkv = rnd(Bn * L, 3 * H * 64, scale=1.5).to(dt)
+    want, lse_want = attn_ref(qkv, Bn, L, H)
+    out, lse = ops.attention_fwd(qkv.to(DEV), Bn, L, H, save_lse=True)
+    tol = dict(rtol=1e-4, atol=1e-4) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(out.float().cpu(), want, **tol)
+    torch.testing.assert_close(lse.cpu(), lse_want, rtol=1e-3, atol=1e-3)
+
+
+def test_attention_large_logits_and_generic_long():
+    # a spiked key must not overflow the un-rescaled softmax (max is taken over the whole row first)
+    Bn, L, H = 1, 129, 1
+    qkv = rnd(L, 192).bfloat16()
+    qkv[5, :64] = 30.0
+    qkv[77, 64:128] = 30.0
+    want, _ = attn_ref(qkv, Bn, L, H)
+    out = ops.attention_fwd(qkv.to(DEV), Bn, L, H)
+    assert torch.isfinite(out.float()).all()
+    torch.testing.assert_close(out.float().cpu(), want, rtol=2e-2, atol=2e-2)
+    qkv = rnd(200, 192).bfloat16()                     # L > 144 takes the generic kernel
+    want, _ = attn_ref(qkv, 1, 200, 1)
+    torch.testing.assert_close(ops.attention_fwd(qkv.to(DEV), 1, 200, 1).float().cpu(), want, rtol=2e-2, atol=2e-2)
+
+
+# ------------------------------------------------------------------------------------------------ embedding / layout
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_im2col_and_embed_tokens(dt):
+    Bn, H, W, Wd = 3, 64, 32, 128
+    spec = O.Spec(img_h=H, img_w=W, width=Wd)
+    img = rnd(Bn, 3, H, W)
+    cols = ops.im2col(img.to(DEV), 16, 16, dt)
+    want = O.patchify(img, spec).reshape(Bn * 8, 768)
+    torch.testing.assert_close(cols.float().cpu(), want.to(dt).float(), rtol=0, atol=0)
+    patch = rnd(Bn * 8, Wd, seed=1).to(dt)
+    cls, pos, ce = rnd(Wd, seed=2), rnd(9, Wd, seed=3), rnd(4, Wd, seed=4)
+    cam = torch.tensor([3, 0, 2])
+    lw, lb = 1 + rnd(Wd, seed=5, scale=0.1), rnd(Wd, seed=6, scale=0.1)
+    for all_tok in (False, True):
+        for use_ln in (True, False):
+            x = torch.cat([cls.expand(Bn, 1, Wd), patch.float().reshape(Bn, 8, Wd)], 1) + pos
+            add = 1.5 * ce[cam][:, None, :]
+            x = x + add if all_tok else torch.cat([x[:, :1] + add, x[:, 1:]], 1)
+            want = O.layer_norm(x, lw, lb, 1e-5) if use_ln else x
+            got, pre, mean, rstd = ops.embed_tokens(patch.to(DEV), cls.to(DEV), pos.to(DEV), ce.to(DEV), cam.to(DEV), 1.5, all_tok,
+                                                    lw.to(DEV) if use_ln else None, lb.to(DEV) if use_ln else None, 1e-5, Bn, 8, save=True)
+            torch.testing.assert_close(got.cpu().reshape(Bn, 9, Wd), want, rtol=1e-5, atol=1e-5)
+            torch.testing.assert_close(pre.cpu().reshape(Bn, 9, Wd), x, rtol=1e-6, atol=1e-6)
+
+
+def test_small_layout_kernels():
+    x = rnd(1000, 7)
+    assert torch.equal(ops.cast_f32_bf16(x.reshape(-1).to(DEV), torch.empty(7000, device=DEV, dtype=torch.bfloat16)).cpu(), x.reshape(-1).bfloat16())
+    xb = x.bfloat16().reshape(-1)
+    assert torch.equal(ops.cast_bf16_f32(xb.to(DEV), torch.empty(7000, device=DEV)).cpu(), xb.float())
+    for dt in (torch.float32, torch.bfloat16):
+        t = rnd(130, 70).to(dt)
+        assert torch.equal(ops.transpose(t.to(DEV)).cpu(), t.t().contiguous())
+    t = rnd(777, 100)
+    torch.testing.assert_close(ops.colsum(t.to(DEV)).cpu(), t.sum(0), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(ops.colsum(t.bfloat16().to(DEV)).cpu(), t.bfloat16().float().sum(0), rtol=1e-4, atol=1e-3)
+    Bn, L, Cd = 4, 9, 64
+    for dt in (torch.float32, torch.bfloat16):
+        tok = rnd(Bn * L, Cd).to(dt)
+        z = ops.pife_pool_cat(tok.to(DEV), Bn, L)
+        tf = tok.float().reshape(Bn, L, Cd)
+        torch.testing.assert_close(z.cpu(), torch.cat([tf[:, 0], tf[:, 1:].mean(1)], -1), rtol=1e-5, atol=1e-5)
+        ori = torch.zeros(Bn, 3 * Cd, device=DEV)
+        ops.get_token0(tok.to(DEV), ori, Cd, 3 * Cd, Bn, L)
+        torch.testing.assert_close(ori.cpu()[:, Cd:2 * Cd], tf[:, 0], rtol=0, atol=0)
+        glob = rnd(Bn, 3 * Cd, seed=2)
+        td = tok.to(DEV).clone()
+        ops.set_token0(td, glob.to(DEV), 2 * Cd, 3 * Cd, Bn, L)
+        want = tf.clone()
+        want[:, 0] = glob[:, 2 * Cd:].to(dt).float()
+        torch.testing.assert_close(td.float().cpu().reshape(Bn, L, Cd), want, rtol=0, atol=0)
+
+
+# ------------------------------------------------------------------------------------------------ HDM / ATMoE pieces
+STREAMS = [(0,), (1,), (2,), (0, 1), (0, 2), (1, 2), (0, 1, 2)]
+
+
+@pytest.mark.parametrize("Bs,L,Cd,Hh,dt", [(3, 9, 128, 2, torch.float32), (2, 129, 512, 8, torch.bfloat16), (2, 5, 768, 12, torch.float32)])
+def test_hdm_softmax_pool(Bs, L, Cd, Hh, dt):
+    ldS = 128
+    S = rnd(3 * Bs * L, ldS, scale=2.0)
+    tok = rnd(3 * Bs * L, Cd, seed=1).to(dt)
+    pooled, psum, probs = ops.hdm_softmax_pool(S.to(DEV), tok.to(DEV), Bs, L, Cd, Hh, ldS, save_probs=True)
+    tf, Sf = tok.float().reshape(3, Bs, L, Cd), S.reshape(3, Bs, L, ldS)
+    for br, st in enumerate(STREAMS):
+        sc = torch.cat([Sf[m][:, :, br * Hh:(br + 1) * Hh] for m in st], 1)            # (Bs, Lk, Hh)
+        x = torch.cat([tf[m] for m in st], 1)                                          # (Bs, Lk, C)
+        p = sc.softmax(1)
+        want = torch.einsum("blh,blc->bhc", p, x)
+        torch.testing.assert_close(pooled[:, br].cpu(), want, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(probs[:, br, :, :len(st) * L].cpu(), p.transpose(1, 2), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(psum.cpu(), torch.ones(Bs, 7, Hh), rtol=1e-5, atol=1e-5)
+
+
+def test_hdm_dropout_is_a_scaled_mask():
+    Bs, L, Cd, Hh, ldS = 4, 129, 128, 2, 128
+    S, tok = rnd(3 * Bs * L, ldS), rnd(3 * Bs * L, Cd, seed=1)
+    _, _, p0 = ops.hdm_softmax_pool(S.to(DEV), tok.to(DEV), Bs, L, Cd, Hh, ldS, save_probs=True)
+    pooled, psum, p1 = ops.hdm_softmax_pool(S.to(DEV), tok.to(DEV), Bs, L, Cd, Hh, ldS, p_drop=0.1, seed=1234, save_probs=True)
+    _, _, p2 = ops.hdm_softmax_pool(S.to(DEV), tok.to(DEV), Bs, L, Cd, Hh, ldS, p_drop=0.1, seed=1234, save_probs=True)
+    assert torch.equal(p1, p2)                                               # counter-based: reproducible for backward
+    kept = p1 != 0
+    valid = p0 > 0
+    frac = 1 - kept[valid].float().mean().item()
+    assert 0.08 < frac < 0.12
+    torch.testing.assert_close(p1[kept], (p0 / 0.9)[kept], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(psum, p1.sum(-1), rtol=1e-5, atol=1e-6)
+    y = torch.zeros(Bs, 7, Cd, device=DEV)
+    bias = rnd(7 * 200, seed=3)
+    ops.hdm_vbias(y, bias.to(DEV), 10, 200, psum, Bs, Cd, Hh)
+    want = torch.stack([bias[10 + br * 200: 10 + br * 200 + Cd] for br in range(7)])[None] * psum.cpu().repeat_interleave(Cd // Hh, -1)
+    torch.testing.assert_close(y.cpu(), want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("Bs,Cd,H", [(5, 128, 4), (3, 512, 8), (2, 768, 12)])
+def test_atmoe_gate_softmax(Bs, Cd, H):
+    q, k = rnd(Bs, Cd), rnd(Bs * 7, Cd, seed=1)
+    d = Cd // H
+    want = (torch.einsum("bhd,bjhd->bhj", q.reshape(Bs, H, d), k.reshape(Bs, 7, H, d)) * d ** -0.5).softmax(-1)
+    got = ops.atmoe_gate_softmax(q.to(DEV), k.to(DEV), Bs, Cd, H)
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-4, atol=1e-5)
