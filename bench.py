@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: tri-modal images/sec of the PIFE -> HDM -> ATMoE hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--mode train|fwd] [--batch B]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+(one rank per GPU, RCCL).  A "step" is one pass of the hot path over one synthetic batch already resident in HBM:
+  mode train (default when the backward kernels are present): forward + backward (+ RCCL gradient all-reduce for N>1)
+       of the RGBNT201 DeMo config at B=128 triplets per GPU  (BASELINE.json configs[2] / configs[3]);
+  mode fwd : eval forward at B=64 triplets per GPU, bf16                      (BASELINE.json configs[1]).
+Rank 0 prints ONE JSON line (contract in the task statement) that also carries
+  "roofline"     : the dominant kernel (bf16 MFMA GEMM) timed live with HIP events on the launch stream,
+  "cpu_baseline" : the CPU oracle (oracle/demo_oracle.py, kind "port") timed on this host for a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=["auto", "train", "fwd"], default="auto")
+    ap.add_argument("--batch", type=int, default=0, help="triplets per GPU (default: 128 train / 64 fwd)")
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def have_backward():
+    try:
+        from demo2_amd.modeling import hip_backward  # noqa: F401
+        return True
+    except ImportError:
+        return False
+
+
+def gemm_roofline(model, step_fn):
+    """Instrumented extra step: every demo_gemm launch that takes the MFMA kernel is bracketed by HIP events
+    on the launch stream (torch's current stream IS the stream handed to the C ABI)."""
+    from demo2_amd import ops, _lib
+    import ctypes as C
+    lib = _lib.load()
+    recs = []
+    orig = lib.demo_gemm
+
+    class Wrapper:
+        def __call__(self, dref, stream):
+            d = dref._obj
+            if lib.demo_gemm_path(C.byref(d)) == 1:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = orig(dref, stream)
+                e1.record()
+                recs.append((e0, e1, 2.0 * d.M * d.N * d.K * d.batch1 * d.batch2))
+                return rc
+            return orig(dref, stream)
+
+    lib.demo_gemm = Wrapper()
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        lib.demo_gemm = orig
+    if not recs:
+        return None
+    tot_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+    flops = sum(f for _, _, f in recs)
+    ach = flops / (tot_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+            "launches_per_step": len(recs), "avg_launch_us": round(tot_ms * 1e3 / len(recs), 1),
+            "gemm_ms_per_step": round(tot_ms, 3), "algorithmic_gflop_per_step": round(flops / 1e9, 1)}
+
+
+def cpu_baseline(mode, seconds):
+    """The CPU restatement (oracle) on this host's cores, bounded sample of the same workload (B=2 batches)."""
+    from oracle import demo_oracle as O
+    from util import synth_batch
+    # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    spec = O.Spec()
+    sd = O.init_state_dict(spec, seed=1)
+    x, cam = synth_batch(2, 256, 128, 4)
+    target = torch.tensor([0, 0])
+    if mode == "train":
+        sd = {k: v.requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+
+    def one():
+        if mode == "train":
+            out = O.model_forward(sd, spec, x, cam, training=True, updates={})
+            O.train_loss(out, target).backward()
+        else:
+            with torch.no_grad():
+                O.model_forward(sd, spec, x, cam)
+    one()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds and n >= 2:
+            break
+    return {"value": round(2 * n / dt, 2), "unit": "triplets/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} {'fwd+bwd' if mode == 'train' else 'eval forward'} passes of the fp32 CPU oracle, RGBNT201 DeMo config, B=2 "
+                      f"({dt:.1f} s)"}
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    a = parse()
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    mode = a.mode if a.mode != "auto" else ("train" if have_backward() else "fwd")
+    B = a.batch or (128 if mode == "train" else 64)
+
+    from demo2_amd.modeling import make_model
+    from oracle import demo_oracle as O      # only for the seeded weight factory + cpu_baseline (checker side)
+    from util import make_cfg, spec_of, synth_batch
+    cfg = make_cfg("RGBNT201")
+    torch.manual_seed(1234)
+    model = make_model(cfg, 171, 4, 0)
+    model.load_state_dict(O.init_state_dict(spec_of(model), seed=1))
+    model = model.to(dev).set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+    x, cam = synth_batch(B, 256, 128, 4, seed=1234 + rank, device=dev)
+    # PK-structured labels: NUM_INSTANCE=4 per identity (configs/RGBNT201/DeMo.yml)
+    target = (torch.arange(B, device=dev) // 4 + rank * (B // 4)) % 171
+
+    if mode == "train":
+        from demo2_amd.modeling.hip_backward import TrainStep
+        stepper = TrainStep(model, cfg, world)
+        model.train()
+
+        def step():
+            stepper.step(x, target, cam)
+    else:
+        model.eval()
+
+        def step():
+            with torch.no_grad():
+                model(x, cam_label=cam, return_pattern=3)
+
+    def fence():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log(f"mode={mode} B={B} world={world}: model on {dev}, starting {a.warmup} warmup steps")
+    for _ in range(a.warmup):
+        step()
+    fence()
+    log("warmup done, timing")
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    log(f"timed region: {dt:.3f} s for {a.steps} steps")
+    roof = cpu = None
+    if rank == 0:
+        roof = gemm_roofline(model, step)
+        log("roofline pass done; cpu baseline next")
+        if world == 1 and not a.no_cpu_baseline:
+            cpu = cpu_baseline(mode, a.cpu_seconds)
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        val = B * world * a.steps / dt
+        flop_per_triplet = 69.99e9 * (3 if mode == "train" else 1)
+        line = {
+            "metric": "tri-modal images/sec " + ("fwd+bwd" if mode == "train" else "fwd"),
+            "value": round(val, 1), "unit": "triplets/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": ("RGBNT201 DeMo.yml (CLIP ViT-B/16 x3 + PIFE + HDM + ATMoE), "
+                                    + ("train step fwd+bwd, " if mode == "train" else "eval forward, ")
+                                    + f"3x({B},3,256,128) per GPU, random-init weights"),
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "mode": mode},
+            "model_tflops": round(val * flop_per_triplet / 1e12, 1),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

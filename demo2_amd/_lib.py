@@ -44,6 +44,7 @@ PROTOTYPES = {
     "demo_abi_version": [],
     "demo_gemm": [C.POINTER(GemmDesc), _P],
     "demo_gemm_desc_size": [],
+    "demo_gemm_path": [C.POINTER(GemmDesc)],
     "demo_cast_f32_bf16": [_P, _P, _L, _P],
     "demo_cast_bf16_f32": [_P, _P, _L, _P],
     "demo_transpose": [_P, _P, _I, _I, _I, _P],

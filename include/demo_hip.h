@@ -64,6 +64,7 @@ typedef struct demo_gemm_desc {
   void* pre_out;          /* optional: value BEFORE `act` (after alpha, bias), indexed and typed like C; saved for backward */
 } demo_gemm_desc;
 int demo_gemm(const demo_gemm_desc* d, void* stream);
+int demo_gemm_path(const demo_gemm_desc* d); /* 1 = bf16 MFMA kernel, 0 = generic kernel (what demo_gemm would pick) */
 int demo_gemm_desc_size(void); /* sizeof(demo_gemm_desc): lets a foreign binding verify its struct layout */
 
 /* ---- elementwise / layout ----------------------------------------------------------------- */

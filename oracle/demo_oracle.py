@@ -395,7 +395,7 @@ def eval_market1501(distmat, q_pids, g_pids, q_camids, g_camids, max_rank: int =
     return cmc, float(np.mean(aps))
 
 
-def r1_map(feats: Tensor, pids, camids, num_query: int, feat_norm: bool = True):
+def r1_map(feats: Tensor, pids, camids, num_query: int, feat_norm: bool = True, max_rank: int = 50):
     """R1_mAP_eval.compute (utils/metrics.py:341-369,395-401)."""
     import numpy as np
     if feat_norm:
@@ -403,7 +403,7 @@ def r1_map(feats: Tensor, pids, camids, num_query: int, feat_norm: bool = True):
     qf, gf = feats[:num_query], feats[num_query:]
     dist = (qf ** 2).sum(1, keepdim=True) + (gf ** 2).sum(1, keepdim=True).t() - 2 * qf @ gf.t()
     pids, camids = np.asarray(pids), np.asarray(camids)
-    return eval_market1501(dist.numpy(), pids[:num_query], pids[num_query:], camids[:num_query], camids[num_query:])
+    return eval_market1501(dist.numpy(), pids[:num_query], pids[num_query:], camids[:num_query], camids[num_query:], max_rank)
 
 
 # --------------------------------------------------------------------------

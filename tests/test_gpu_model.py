@@ -137,6 +137,7 @@ def test_synthetic_map_parity_bf16():
         with torch.no_grad():
             feats_hip.append(m({k: v.to(DEV) for k, v in xb.items()}, cam_label=cam[i:i + 8].to(DEV)).cpu())
     nq = 12
-    cmc_r, map_r = O.r1_map(torch.cat(feats_ref), pid, camid, nq)
-    cmc_h, map_h = O.r1_map(torch.cat(feats_hip), pid, camid, nq)
+    # eval_func needs >= max_rank kept gallery items per query (utils/metrics.py:149,165): 20 gallery items -> rank 10
+    cmc_r, map_r = O.r1_map(torch.cat(feats_ref), pid, camid, nq, max_rank=10)
+    cmc_h, map_h = O.r1_map(torch.cat(feats_hip), pid, camid, nq, max_rank=10)
     assert abs(map_r - map_h) * 100 <= 0.1 and abs(cmc_r[0] - cmc_h[0]) * 100 <= 0.1, (map_r, map_h, cmc_r[0], cmc_h[0])
