@@ -52,13 +52,24 @@ PROTOTYPES = {
     "demo_im2col": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "demo_embed_tokens": [_P, _I, _P, _P, _P, _P, _F, _I, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P],
     "demo_layernorm_fwd": [_P, _P, _P, _F, _P, _I, _P, _P, _I, _I, _P],
-    "demo_layernorm_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P],
+    "demo_layernorm_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P],
+    "demo_adam_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _P],
     "demo_batchnorm_fwd": [_P, _P, _P, _P, _P, _I, _F, _F, _P, _I, _P, _P, _I, _I, _I, _I, _I, _L, _L, _P, _P],
     "demo_attention_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "demo_pife_pool_cat": [_P, _I, _P, _I, _I, _I, _P],
     "demo_set_token0": [_P, _I, _P, _L, _I, _I, _I, _P],
     "demo_get_token0": [_P, _I, _P, _L, _I, _I, _I, _P],
-    "demo_hdm_softmax_pool": [_P, _L, _P, _I, _P, _P, _P, _I, _I, _I, _I, _F, _U64, _P],
+    "demo_hdm_softmax_pool": [_P, _L, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _U64, _P],
+    "demo_hdm_softmax_pool_bwd": [_P, _P, _P, _P, _I, _P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _U64, _P],
+    "demo_hdm_vbias_bwd": [_P, _P, _L, _P, _P, _P, _I, _I, _I, _P],
+    "demo_atmoe_gate_softmax_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "demo_gemm_tn_bf16": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _F, _I, _P],
+    "demo_attention_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "demo_embed_tokens_bwd": [_P, _P, _F, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P],
+    "demo_act_bwd": [_P, _P, _I, _P, _L, _P],
+    "demo_batchnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _L, _P, _P, _P],
+    "demo_token0_grad": [_P, _P, _L, _I, _I, _I, _P],
+    "demo_tokens_grad": [_P, _P, _L, _P, _L, _I, _P, _I, _I, _I, _I, _P],
     "demo_hdm_vbias": [_P, _P, _L, _P, _I, _I, _I, _P],
     "demo_atmoe_gate_softmax": [_P, _P, _P, _I, _I, _I, _P],
 }

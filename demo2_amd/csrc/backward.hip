@@ -1,0 +1,386 @@
+// Backward kernels of the small (HBM / launch bound) stages: token embedding, activations, BatchNorm1d (plain and the
+// grouped + gated ATMoE form), ATMoE gate softmax, HDM softmax-pool, PIFE pooling.  All math fp32.
+#include "common.h"
+
+namespace {
+
+constexpr int HH_MAX = 12;
+__constant__ int b_nstreams[7] = {1, 1, 1, 2, 2, 2, 3};
+__constant__ int b_streams[7][3] = {{0, 0, 0}, {1, 0, 0}, {2, 0, 0}, {0, 1, 0}, {0, 2, 0}, {1, 2, 0}, {0, 1, 2}};
+// branches attending modality m, and the position of m inside that branch's concatenation
+__constant__ int b_mbranch[3][4] = {{0, 3, 4, 6}, {1, 3, 5, 6}, {2, 4, 5, 6}};
+__constant__ int b_mpos[3][4] = {{0, 0, 0, 0}, {0, 1, 0, 1}, {0, 1, 1, 2}};
+
+__device__ __forceinline__ uint32_t rng_hash(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ULL * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return (uint32_t)((z ^ (z >> 31)) >> 32);
+}
+
+// ---- token embedding backward: block per token position t, threads over channels --------------------------------
+template <typename TP>
+__global__ __launch_bounds__(256) void embed_tokens_bwd_kernel(const float* __restrict__ dpre, const int64_t* __restrict__ cam,
+                                                               float cam_scale, int cam_all, TP* __restrict__ dpatch,
+                                                               float* __restrict__ dcls, float* __restrict__ dpos,
+                                                               float* __restrict__ dcam, int Bn, int np, int W) {
+  const int t = blockIdx.x, L = np + 1;
+  for (int c = threadIdx.x; c < W; c += blockDim.x) {
+    float s = 0.f;
+    for (int b = 0; b < Bn; ++b) {
+      const float v = dpre[((int64_t)b * L + t) * W + c];
+      s += v;
+      if (t > 0) io<TP>::st(dpatch + ((int64_t)b * np + (t - 1)) * W + c, v);
+      if (dcam && cam && (cam_all || t == 0)) atomicAdd(&dcam[cam[b] * (int64_t)W + c], cam_scale * v);
+    }
+    if (dpos) dpos[(int64_t)t * W + c] += s;
+    if (t == 0 && dcls) dcls[c] += s;
+  }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, int kind,
+                                                      float* __restrict__ dx, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dx[i] = dy[i] * act_grad(pre[i], kind);
+}
+
+// ---- BatchNorm1d backward (training statistics); thread per feature ----------------------------------------------
+// forward: y = ((x - mean) * invstd * w + b) * gate
+__global__ __launch_bounds__(64) void batchnorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ w, const float* __restrict__ b,
+                                                           const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                                           float* __restrict__ dx, int accumulate_dx, float* __restrict__ dw,
+                                                           float* __restrict__ db, int Bn, int F, int gsz, int n_inner, int n_outer,
+                                                           int64_t pstride, const float* __restrict__ gate, float* __restrict__ dgate) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  int64_t pi = f;
+  int gi = 0, go = 0;
+  if (gsz > 0) {
+    const int g = f / gsz, k = f - g * gsz;
+    gi = g % n_inner; go = g / n_inner;
+    pi = ((int64_t)gi * n_outer + go) * pstride + k;
+  }
+  const float mean = save_mean[f], invstd = save_invstd[f], wv = w[pi], bv = b ? b[pi] : 0.f;
+  float sdy = 0.f, sdyx = 0.f;
+  for (int r = 0; r < Bn; ++r) {
+    const float xh = (x[(int64_t)r * F + f] - mean) * invstd;
+    float d = dy[(int64_t)r * F + f];
+    if (gate) {
+      const int64_t gidx = ((int64_t)r * n_inner + gi) * n_outer + go;
+      if (dgate) atomicAdd(&dgate[gidx], d * (xh * wv + bv));
+      d *= gate[gidx];
+    }
+    sdy += d;
+    sdyx += d * xh;
+  }
+  if (dw) dw[pi] += sdyx;
+  if (db) db[pi] += sdy;
+  const float inv = 1.f / (float)Bn;
+  for (int r = 0; r < Bn; ++r) {
+    const float xh = (x[(int64_t)r * F + f] - mean) * invstd;
+    float d = dy[(int64_t)r * F + f];
+    if (gate) d *= gate[((int64_t)r * n_inner + gi) * n_outer + go];
+    float v = wv * invstd * (d - sdy * inv - xh * sdyx * inv);
+    if (accumulate_dx) v += dx[(int64_t)r * F + f];
+    dx[(int64_t)r * F + f] = v;
+  }
+}
+
+// ---- ATMoE gate softmax backward: block per sample, wave per head ---------------------------------------------------
+__global__ __launch_bounds__(256) void atmoe_gate_softmax_bwd_kernel(const float* __restrict__ dgates, const float* __restrict__ gates,
+                                                                     const float* __restrict__ q, const float* __restrict__ k,
+                                                                     float* __restrict__ dq, float* __restrict__ dk, int C, int H) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = C / H;
+  const float scale = rsqrtf((float)d);
+  for (int h = wave; h < H; h += 4) {
+    float gt[7], dl[7];
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      gt[j] = gates[((int64_t)b * H + h) * 7 + j];
+      dl[j] = dgates[((int64_t)b * H + h) * 7 + j];
+      dot += gt[j] * dl[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) dl[j] = gt[j] * (dl[j] - dot) * scale;     // d logits (scaled)
+    for (int e = lane; e < d; e += 64) {
+      const float qv = q[(int64_t)b * C + h * d + e];
+      float aq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int64_t ki = ((int64_t)b * 7 + j) * C + h * d + e;
+        aq = fmaf(dl[j], k[ki], aq);
+        dk[ki] = dl[j] * qv;
+      }
+      dq[(int64_t)b * C + h * d + e] = aq;
+    }
+  }
+}
+
+// ---- HDM softmax-pool backward: block per (sample, modality) ----------------------------------------------------------
+// forward (per branch br, head h over the concatenated streams): p = softmax(s); P = dropout(p); pooled = sum P_l x_l; psum = sum P_l
+// backward:  dP_l = dpooled . x_l + dpsum ;  rowdot = sum_l P_l dP_l = dpooled . pooled + dpsum * psum ;
+//            ds_l = P_l dP_l - p_l rowdot ;  dx_l = sum_{br,h} P_l dpooled
+template <typename T>
+__global__ __launch_bounds__(256) void hdm_softmax_pool_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ dpsum,
+                                                                   const float* __restrict__ probs, const T* __restrict__ tok,
+                                                                   const float* __restrict__ pooled, const float* __restrict__ psum,
+                                                                   float* __restrict__ dS, int64_t ldS, float* __restrict__ dtok,
+                                                                   int Bs, int L, int C, int Hh, float p_drop, uint64_t seed) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int b = blockIdx.x, m = blockIdx.y;
+  const int L3 = 3 * L;
+  float* dpl = sm;                          // [4][Hh][C]
+  float* rowdot = sm + 4 * Hh * C;          // [4][Hh]
+  float* dps = rowdot + 4 * HH_MAX;         // [4][Hh]
+  for (int i = threadIdx.x; i < 4 * Hh * C; i += blockDim.x) {
+    const int s = i / (Hh * C), rem = i - s * Hh * C;
+    dpl[i] = dpooled[((int64_t)(b * 7 + b_mbranch[m][s]) * Hh) * C + rem];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = wave; i < 4 * Hh; i += 4) {
+    const int s = i / Hh, h = i - s * Hh;
+    const int br = b_mbranch[m][s];
+    const float* pl = pooled + ((int64_t)(b * 7 + br) * Hh + h) * C;
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a = fmaf(dpl[(s * Hh + h) * C + c], pl[c], a);
+    a = wave_sum(a);
+    if (lane == 0) {
+      const float dp_ = dpsum ? dpsum[(int64_t)(b * 7 + br) * Hh + h] : 0.f;
+      rowdot[s * HH_MAX + h] = a + dp_ * psum[(int64_t)(b * 7 + br) * Hh + h];
+      dps[s * HH_MAX + h] = dp_;
+    }
+  }
+  __syncthreads();
+  const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  const uint32_t thresh = p_drop > 0.f ? (uint32_t)(p_drop * 4294967296.0) : 0u;
+  const int nper = (C + 63) / 64;           // channels per lane (<= 16 for C <= 1024)
+  for (int l = wave; l < L; l += 4) {
+    const int64_t row = (int64_t)(m * Bs + b) * L + l;
+    float xv[16], dxv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = lane + i * 64;
+      xv[i] = (i < nper && c < C) ? io<T>::ld(tok + row * C + c) : 0.f;
+      dxv[i] = 0.f;
+    }
+    float* dsrow = dS + row * ldS;
+    for (int c = lane; c < ldS; c += 64) dsrow[c] = 0.f;      // columns of branches that do not attend this modality
+    __builtin_amdgcn_wave_barrier();
+    for (int s = 0; s < 4; ++s) {
+      const int br = b_mbranch[m][s];
+      const int lk = b_mpos[m][s] * L + l;
+      for (int h = 0; h < Hh; ++h) {
+        const float* dp_h = dpl + (s * Hh + h) * C;
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int c = lane + i * 64;
+          if (i < nper && c < C) a = fmaf(dp_h[c], xv[i], a);
+        }
+        a = wave_sum(a) + dps[s * HH_MAX + h];                 // dP_l
+        const int64_t pidx = ((int64_t)(b * 7 + br) * Hh + h) * L3 + lk;
+        const float p = probs[pidx];
+        float P = p;
+        if (p_drop > 0.f) P = (rng_hash(seed, (uint64_t)pidx) >= thresh) ? p * keep_scale : 0.f;
+        if (lane == 0) dsrow[br * Hh + h] = P * a - p * rowdot[s * HH_MAX + h];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int c = lane + i * 64;
+          if (i < nper && c < C) dxv[i] = fmaf(P, dp_h[c], dxv[i]);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = lane + i * 64;
+      if (i < nper && c < C) dtok[row * C + c] = dxv[i];
+    }
+  }
+}
+
+// do (Bs,7,C): dbias[br*stride + c] += sum_b do*psum ; dpsum[b,br,h] = sum_{c in head h} do * bias
+__global__ __launch_bounds__(256) void hdm_vbias_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ bias, int64_t bias_stride,
+                                                            const float* __restrict__ psum, float* __restrict__ dbias,
+                                                            float* __restrict__ dpsum, int Bs, int C, int Hh) {
+  const int br = blockIdx.x;
+  const int dh = C / Hh;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float bv = bias[br * bias_stride + c];
+    float s = 0.f;
+    for (int b = 0; b < Bs; ++b) {
+      const float d = dy[((int64_t)b * 7 + br) * C + c];
+      s = fmaf(d, psum[((int64_t)b * 7 + br) * Hh + c / dh], s);
+      atomicAdd(&dpsum[((int64_t)b * 7 + br) * Hh + c / dh], d * bv);
+    }
+    dbias[br * bias_stride + c] += s;
+  }
+}
+
+// out[b, c] += src[(b*L + 0), c]   (row-0 gradient of a token stream -> the (B, ld) global-feature gradient)
+__global__ __launch_bounds__(128) void token0_grad_kernel(const float* __restrict__ dtok, float* __restrict__ out, int64_t ld, int L, int C) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) out[(int64_t)b * ld + c] += dtok[(int64_t)b * L * C + c];
+}
+
+// final token gradient (dtype T):  row 0 = dcls[b,:]   (+ dtok row 0 when keep_row0)
+//                                  row l>=1 = dtok[b,l,:] + dmean[b,:] / (L-1)
+template <typename T>
+__global__ __launch_bounds__(256) void tokens_grad_kernel(const float* __restrict__ dtok, const float* __restrict__ dcls, int64_t cls_ld,
+                                                          const float* __restrict__ dmean, int64_t mean_ld, int keep_row0,
+                                                          T* __restrict__ out, int L, int C) {
+  const int b = blockIdx.x;
+  const float inv = 1.f / (float)(L - 1);
+  for (int i = threadIdx.x; i < L * (C >> 2); i += blockDim.x) {
+    const int l = i / (C >> 2), c4 = (i - l * (C >> 2)) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (dtok && (l > 0 || keep_row0)) v = *reinterpret_cast<const float4*>(dtok + ((int64_t)b * L + l) * C + c4);
+    if (l == 0) {
+      if (dcls) {
+        const float4 a = *reinterpret_cast<const float4*>(dcls + (int64_t)b * cls_ld + c4);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+    } else if (dmean) {
+      const float4 a = *reinterpret_cast<const float4*>(dmean + (int64_t)b * mean_ld + c4);
+      v.x += a.x * inv; v.y += a.y * inv; v.z += a.z * inv; v.w += a.w * inv;
+    }
+    io<T>::st4(out + ((int64_t)b * L + l) * C + c4, v);
+  }
+}
+
+// Fused flat Adam: one pass over the flat fp32 parameter / gradient / moment buffers; also emits the bf16 weight
+// shadow for the next forward and clears the gradient (torch.optim.Adam update rule, L2 decay added to the gradient).
+__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, bf16_t* __restrict__ shadow, int64_t n4, float lr,
+                                                        float b1, float b2, float eps, float wd, float bc1, float bc2_rsqrt,
+                                                        int zero_grad) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pv = *reinterpret_cast<const float4*>(p + i * 4);
+    const float4 gv = *reinterpret_cast<const float4*>(g + i * 4);
+    float4 mv = *reinterpret_cast<const float4*>(m + i * 4);
+    float4 vv = *reinterpret_cast<const float4*>(v + i * 4);
+    float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
+    float ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gg = ga[e] + wd * pa[e];
+      ma[e] = b1 * ma[e] + (1.f - b1) * gg;
+      va[e] = b2 * va[e] + (1.f - b2) * gg * gg;
+      const float denom = sqrtf(va[e]) * bc2_rsqrt + eps;
+      pa[e] -= (lr / bc1) * (ma[e] / denom);
+    }
+    pv = make_float4(pa[0], pa[1], pa[2], pa[3]);
+    *reinterpret_cast<float4*>(p + i * 4) = pv;
+    *reinterpret_cast<float4*>(m + i * 4) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+    *reinterpret_cast<float4*>(v + i * 4) = make_float4(va[0], va[1], va[2], va[3]);
+    if (shadow) io<bf16_t>::st4(shadow + i * 4, pv);
+    if (zero_grad) *reinterpret_cast<float4*>(g + i * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+}  // namespace
+
+extern "C" int demo_adam_step(float* p, float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, int32_t step, int32_t zero_grad, void* stream) {
+  DEMO_REQUIRE(n % 4 == 0 && step >= 1, "demo_adam_step: n must be a multiple of 4 and step >= 1");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = 1.f - powf(beta2, (float)step);
+  int64_t grid = cdiv64(n / 4, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow_bf16, n / 4, lr,
+                     beta1, beta2, eps, weight_decay, bc1, 1.f / sqrtf(bc2), zero_grad);
+  DEMO_LAUNCH_CHECK("demo_adam_step");
+  return 0;
+}
+
+extern "C" int demo_embed_tokens_bwd(const float* dpre, const int64_t* cam, float cam_scale, int32_t cam_all_tokens, void* dpatch,
+                                     int32_t dt_patch, float* dcls, float* dpos, float* dcam, int32_t Bn, int32_t np, int32_t W,
+                                     void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (dt_patch == DEMO_BF16)
+    hipLaunchKernelGGL(embed_tokens_bwd_kernel<bf16_t>, dim3(np + 1), dim3(256), 0, s, dpre, cam, cam_scale, cam_all_tokens,
+                       (bf16_t*)dpatch, dcls, dpos, dcam, Bn, np, W);
+  else
+    hipLaunchKernelGGL(embed_tokens_bwd_kernel<float>, dim3(np + 1), dim3(256), 0, s, dpre, cam, cam_scale, cam_all_tokens,
+                       (float*)dpatch, dcls, dpos, dcam, Bn, np, W);
+  DEMO_LAUNCH_CHECK("demo_embed_tokens_bwd");
+  return 0;
+}
+
+extern "C" int demo_act_bwd(const float* dy, const float* pre, int32_t kind, float* dx, int64_t n, void* stream) {
+  int64_t g = cdiv64(n, 256);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, dy, pre, kind, dx, n);
+  DEMO_LAUNCH_CHECK("demo_act_bwd");
+  return 0;
+}
+
+extern "C" int demo_batchnorm_bwd(const float* dy, const float* x, const float* w, const float* b, const float* save_mean,
+                                  const float* save_invstd, float* dx, int32_t accumulate_dx, float* dw, float* db, int32_t Bn,
+                                  int32_t F, int32_t gsz, int32_t n_inner, int32_t n_outer, int64_t pstride, const float* gate,
+                                  float* dgate, void* stream) {
+  DEMO_REQUIRE(gsz == 0 || (F % gsz == 0 && (F / gsz) == n_inner * n_outer), "demo_batchnorm_bwd: bad grouping");
+  DEMO_REQUIRE(!gate || (gsz > 0 && b), "demo_batchnorm_bwd: gate requires grouping and the bias");
+  hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3((unsigned)cdiv64(F, 64)), dim3(64), 0, (hipStream_t)stream, dy, x, w, b, save_mean,
+                     save_invstd, dx, accumulate_dx, dw, db, Bn, F, gsz, n_inner, n_outer, pstride, gate, dgate);
+  DEMO_LAUNCH_CHECK("demo_batchnorm_bwd");
+  return 0;
+}
+
+extern "C" int demo_atmoe_gate_softmax_bwd(const float* dgates, const float* gates, const float* q, const float* k, float* dq,
+                                           float* dk, int32_t Bs, int32_t C, int32_t H, void* stream) {
+  hipLaunchKernelGGL(atmoe_gate_softmax_bwd_kernel, dim3(Bs), dim3(256), 0, (hipStream_t)stream, dgates, gates, q, k, dq, dk, C, H);
+  DEMO_LAUNCH_CHECK("demo_atmoe_gate_softmax_bwd");
+  return 0;
+}
+
+extern "C" int demo_hdm_softmax_pool_bwd(const float* dpooled, const float* dpsum, const float* probs, const void* tokens, int32_t dt,
+                                         const float* pooled, const float* psum, float* dS, int64_t ldS, float* dtokens, int32_t Bs,
+                                         int32_t L, int32_t C, int32_t Hh, float p_drop, uint64_t seed, void* stream) {
+  DEMO_REQUIRE(Hh >= 1 && Hh <= HH_MAX && C <= 1024 && ldS >= 7 * Hh, "demo_hdm_softmax_pool_bwd: unsupported shape");
+  const size_t shm = sizeof(float) * (4 * (size_t)Hh * C + 8 * HH_MAX);
+  DEMO_REQUIRE(shm <= 160 * 1024, "demo_hdm_softmax_pool_bwd: needs %zu B of LDS", shm);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = dt == DEMO_BF16
+      ? hipFuncSetAttribute((const void*)hdm_softmax_pool_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)
+      : hipFuncSetAttribute((const void*)hdm_softmax_pool_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  if (e != hipSuccess) DEMO_FAIL(-2, "demo_hdm_softmax_pool_bwd: cannot reserve %zu B of LDS: %s", shm, hipGetErrorString(e));
+  dim3 grid(Bs, 3);
+  if (dt == DEMO_BF16)
+    hipLaunchKernelGGL(hdm_softmax_pool_bwd_kernel<bf16_t>, grid, dim3(256), shm, s, dpooled, dpsum, probs, (const bf16_t*)tokens, pooled,
+                       psum, dS, ldS, dtokens, Bs, L, C, Hh, p_drop, seed);
+  else
+    hipLaunchKernelGGL(hdm_softmax_pool_bwd_kernel<float>, grid, dim3(256), shm, s, dpooled, dpsum, probs, (const float*)tokens, pooled,
+                       psum, dS, ldS, dtokens, Bs, L, C, Hh, p_drop, seed);
+  DEMO_LAUNCH_CHECK("demo_hdm_softmax_pool_bwd");
+  return 0;
+}
+
+extern "C" int demo_hdm_vbias_bwd(const float* dy, const float* bias, int64_t bias_stride, const float* psum, float* dbias, float* dpsum,
+                                  int32_t Bs, int32_t C, int32_t Hh, void* stream) {
+  hipLaunchKernelGGL(hdm_vbias_bwd_kernel, dim3(7), dim3(256), 0, (hipStream_t)stream, dy, bias, bias_stride, psum, dbias, dpsum, Bs, C, Hh);
+  DEMO_LAUNCH_CHECK("demo_hdm_vbias_bwd");
+  return 0;
+}
+
+extern "C" int demo_token0_grad(const float* dtokens, float* out, int64_t out_ld, int32_t Bn, int32_t L, int32_t C, void* stream) {
+  hipLaunchKernelGGL(token0_grad_kernel, dim3(Bn), dim3(128), 0, (hipStream_t)stream, dtokens, out, out_ld, L, C);
+  DEMO_LAUNCH_CHECK("demo_token0_grad");
+  return 0;
+}
+
+extern "C" int demo_tokens_grad(const float* dtok, const float* dcls, int64_t cls_ld, const float* dmean, int64_t mean_ld,
+                                int32_t keep_row0, void* out, int32_t dt, int32_t Bn, int32_t L, int32_t C, void* stream) {
+  DEMO_REQUIRE(C % 4 == 0 && L >= 2, "demo_tokens_grad: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  if (dt == DEMO_BF16)
+    hipLaunchKernelGGL(tokens_grad_kernel<bf16_t>, dim3(Bn), dim3(256), 0, s, dtok, dcls, cls_ld, dmean, mean_ld, keep_row0, (bf16_t*)out, L, C);
+  else
+    hipLaunchKernelGGL(tokens_grad_kernel<float>, dim3(Bn), dim3(256), 0, s, dtok, dcls, cls_ld, dmean, mean_ld, keep_row0, (float*)out, L, C);
+  DEMO_LAUNCH_CHECK("demo_tokens_grad");
+  return 0;
+}

@@ -27,7 +27,7 @@ __device__ __forceinline__ uint32_t rng_hash(uint64_t seed, uint64_t idx) {
 template <typename T>
 __global__ __launch_bounds__(256) void hdm_softmax_pool_kernel(const float* __restrict__ S, int64_t ldS, const T* __restrict__ tok,
                                                                float* __restrict__ pooled, float* __restrict__ psum,
-                                                               float* __restrict__ probs, int Bs, int L, int C, int Hh,
+                                                               float* __restrict__ probs, float* __restrict__ probs_post, int Bs, int L, int C, int Hh,
                                                                float p_drop, uint64_t seed) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int b = blockIdx.x, br = blockIdx.y;
@@ -68,12 +68,15 @@ __global__ __launch_bounds__(256) void hdm_softmax_pool_kernel(const float* __re
         const uint32_t u = rng_hash(seed, ((uint64_t)(b * 7 + br) * Hh + h) * L3 + i);
         p = (u >= thresh) ? p * keep_scale : 0.f;
       }
+      if (probs) probs[((int64_t)(b * 7 + br) * Hh + h) * L3 + i] = ph[i] * inv;     // softmax BEFORE dropout (backward needs it)
       ph[i] = p;
       kept += p;
-      if (probs) probs[((int64_t)(b * 7 + br) * Hh + h) * L3 + i] = p;
+      if (probs_post) probs_post[((int64_t)(b * 7 + br) * Hh + h) * L3 + i] = p;
     }
-    if (probs)
-      for (int i = Lk + lane; i < L3; i += 64) probs[((int64_t)(b * 7 + br) * Hh + h) * L3 + i] = 0.f;
+    for (int i = Lk + lane; i < L3; i += 64) {
+      if (probs) probs[((int64_t)(b * 7 + br) * Hh + h) * L3 + i] = 0.f;
+      if (probs_post) probs_post[((int64_t)(b * 7 + br) * Hh + h) * L3 + i] = 0.f;
+    }
     kept = wave_sum(kept);
     if (lane == 0 && psum) psum[(int64_t)(b * 7 + br) * Hh + h] = kept;
   }
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void atmoe_gate_softmax_kernel(const float* __
 
 }  // namespace
 
-extern "C" int demo_hdm_softmax_pool(const float* S, int64_t ldS, const void* tokens, int32_t dt, float* pooled, float* psum, float* probs,
+extern "C" int demo_hdm_softmax_pool(const float* S, int64_t ldS, const void* tokens, int32_t dt, float* pooled, float* psum, float* probs, float* probs_post,
                                      int32_t Bs, int32_t L, int32_t C, int32_t Hh, float p_drop, uint64_t seed, void* stream) {
   DEMO_REQUIRE(Hh >= 1 && Hh <= HH_MAX, "demo_hdm_softmax_pool: heads=%d unsupported (<=%d)", Hh, HH_MAX);
   DEMO_REQUIRE(C % 4 == 0 && C / 4 <= 256 && C >= 4, "demo_hdm_softmax_pool: C=%d unsupported", C);
@@ -176,9 +179,9 @@ extern "C" int demo_hdm_softmax_pool(const float* S, int64_t ldS, const void* to
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(Bs, 7);
   if (dt == DEMO_BF16)
-    hipLaunchKernelGGL(hdm_softmax_pool_kernel<bf16_t>, grid, dim3(256), shm, s, S, ldS, (const bf16_t*)tokens, pooled, psum, probs, Bs, L, C, Hh, p_drop, seed);
+    hipLaunchKernelGGL(hdm_softmax_pool_kernel<bf16_t>, grid, dim3(256), shm, s, S, ldS, (const bf16_t*)tokens, pooled, psum, probs, probs_post, Bs, L, C, Hh, p_drop, seed);
   else
-    hipLaunchKernelGGL(hdm_softmax_pool_kernel<float>, grid, dim3(256), shm, s, S, ldS, (const float*)tokens, pooled, psum, probs, Bs, L, C, Hh, p_drop, seed);
+    hipLaunchKernelGGL(hdm_softmax_pool_kernel<float>, grid, dim3(256), shm, s, S, ldS, (const float*)tokens, pooled, psum, probs, probs_post, Bs, L, C, Hh, p_drop, seed);
   DEMO_LAUNCH_CHECK("demo_hdm_softmax_pool");
   return 0;
 }

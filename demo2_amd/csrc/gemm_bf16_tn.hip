@@ -1,0 +1,188 @@
+// bf16 MFMA GEMM with BOTH operands reduction-major:  C[Mo,No] (+)= alpha * sum_r A[r,Mo] * B[r,No]
+// This is the weight-gradient product dW = dY^T X of every nn.Linear: A = dY (rows, N), B = X (rows, K),
+// both exactly as the forward pass left them in HBM (row-major, rows = tokens) -- no transposed copies of
+// activations are ever made.
+//
+//   * tile 128 (Mo) x 128 (No) x 64 (reduction rows) per 256-thread workgroup; an operand tile is 64 rows of
+//     256 B, staged with global_load_lds_dwordx4 (4 rows per wave instruction), double buffered;
+//   * MFMA fragments need 8 consecutive REDUCTION indices per lane, i.e. a column of the staged tile:
+//     ds_read_b64_tr_b16 (the gfx950 transposing LDS read) delivers them, two reads per fragment;
+//   * 256-B rows put a column of 16-B chunks on one bank group: a half-wave's transposed read touches rows
+//     {8g+q : g in a pair, q<4} x 2 chunks, so chunk index ^= 2*(row&3) + 8*((row>>3)&1) (applied on the per-lane
+//     source address of the LDS-DMA and on the read) spreads them over all 16 chunk positions -> conflict free;
+//   * the reduction dimension is the long one here (tokens: 24768 at B=64) while Mo x No is only 36..144 tiles,
+//     so the grid splits the reduction (split-K) and combines with fp32 atomics into the gradient buffer.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BK * 256;          // 16 KiB per operand tile
+constexpr int BUF_BYTES = 2 * TILE_BYTES;
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+struct TArgs {
+  const bf16_t* A;
+  const bf16_t* B;
+  float* C;
+  int Mo, No, Kr;
+  int64_t lda, ldb, ldc;
+  int splitk, kper;     // kper = reduction rows per split (multiple of BK)
+  float alpha;
+  int ntm, ntn;
+  int use_atomics;      // 1: atomicAdd into C; 0: C = (accumulate ? C : 0) + result with plain stores
+  int accumulate;
+};
+
+// LDS-DMA staging of a full 64-row tile: rows [k0, k0+64) x cols [c0, c0+128)
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int64_t ld, int k0, int c0, char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int seg = j * 4 + wave;               // 1 KiB = 4 rows
+    const int r = seg * 4 + (lane >> 4);
+    const int c = (lane & 15) ^ (((r & 3) << 1) | (((r >> 3) & 1) << 3));
+    const bf16_t* src = G + (int64_t)(k0 + r) * ld + c0 + c * 8;
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(lds_tile + seg * 1024), 16, 0, 0);
+  }
+}
+// register-staged variant for the (single) partial tile at the end of the reduction: rows >= k_end read as zero
+__device__ __forceinline__ void stage_tile_tail(const bf16_t* __restrict__ G, int64_t ld, int k0, int k_end, int c0, char* lds_tile,
+                                                int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int seg = j * 4 + wave;
+    const int r = seg * 4 + (lane >> 4);
+    const int c = (lane & 15) ^ (((r & 3) << 1) | (((r >> 3) & 1) << 3));
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (k0 + r < k_end) v = *reinterpret_cast<const uint4*>(G + (int64_t)(k0 + r) * ld + c0 + c * 8);
+    *reinterpret_cast<uint4*>(lds_tile + seg * 1024 + lane * 16) = v;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const TArgs p) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * BUF_BYTES];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tile = blockIdx.x;
+  const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int ks = blockIdx.y * p.kper;
+  const int ke = min(p.Kr, ks + p.kper);
+  if (ks >= ke) return;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // transposed-read addressing: lane (g, idx=4q+pp): row 8g+q (+4), 8-B piece at column 4*pp of a 16-column block
+  const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
+  const int trow = 8 * g + q;                         // row inside a 32-row k-step (first read); second read = +4
+  const int sw0 = (q << 1) | ((g & 1) << 3), sw1 = sw0;  // swizzle of row 8g+q and of row 8g+q+4 (bit 2 of the row is not used)
+  const int half = (pp & 1) << 3, csub = pp >> 1;
+
+  const int nk = (ke - ks + BK - 1) / BK;
+  auto stage = [&](int t, char* buf) {
+    const int k0 = ks + t * BK;
+    if (k0 + BK <= ke) {
+      stage_tile(p.A, p.lda, k0, m0, buf, wave, lane);
+      stage_tile(p.B, p.ldb, k0, n0, buf + TILE_BYTES, wave, lane);
+    } else {
+      stage_tile_tail(p.A, p.lda, k0, ke, m0, buf, wave, lane);
+      stage_tile_tail(p.B, p.ldb, k0, ke, n0, buf + TILE_BYTES, wave, lane);
+    }
+  };
+  stage(0, smem);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < nk; ++t) {
+    char* cur = smem + (t & 1) * BUF_BYTES;
+    if (t + 1 < nk) stage(t + 1, smem + ((t + 1) & 1) * BUF_BYTES);
+    const char* la = cur;
+    const char* lb = cur + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int rbase = (kk * 32 + trow) * 256;
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = wr * 8 + i * 2 + csub;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(la + rbase + ((c ^ sw0) << 4) + half));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(la + rbase + 1024 + ((c ^ sw1) << 4) + half));
+        af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = wc * 8 + j * 2 + csub;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lb + rbase + ((c ^ sw0) << 4) + half));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lb + rbase + 1024 + ((c ^ sw1) << 4) + half));
+        bfr[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // D[row = m_local = 4g + reg][col = n_local = lane & 15]: per register 4 rows x 64 contiguous bytes
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wc * 64 + j * 16 + idx;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wr * 64 + i * 16 + 4 * g + r;
+        float* c = p.C + (int64_t)m * p.ldc + n;
+        const float v = acc[i][j][r] * p.alpha;
+        if (p.use_atomics) atomicAdd(c, v);
+        else *c = p.accumulate ? *c + v : v;
+      }
+    }
+  }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int demo_gemm_tn_bf16(const void* A, const void* B, float* C, int32_t Mo, int32_t No, int32_t Kr, int64_t lda, int64_t ldb,
+                                 int64_t ldc, float alpha, int32_t accumulate, void* stream) {
+  DEMO_REQUIRE(A && B && C, "demo_gemm_tn_bf16: null operand");
+  DEMO_REQUIRE(Mo > 0 && No > 0 && Kr > 0 && Mo % BM == 0 && No % BN == 0, "demo_gemm_tn_bf16: Mo=%d No=%d must be multiples of 128", Mo, No);
+  DEMO_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && al16(A) && al16(B), "demo_gemm_tn_bf16: operands must be 16-B aligned with ld %% 8 == 0");
+  hipStream_t s = (hipStream_t)stream;
+  TArgs p;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
+  p.Mo = Mo; p.No = No; p.Kr = Kr; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.alpha = alpha;
+  p.ntm = Mo / BM; p.ntn = No / BN;
+  const int tiles = p.ntm * p.ntn;
+  const int ktiles = (Kr + BK - 1) / BK;
+  int splitk = 1;
+  if (tiles < 512) splitk = (512 + tiles - 1) / tiles;     // aim at ~2 workgroups per CU
+  if (splitk > ktiles) splitk = ktiles;
+  if (splitk > 32) splitk = 32;
+  const int kt_per = (ktiles + splitk - 1) / splitk;
+  p.kper = kt_per * BK;
+  p.splitk = (ktiles + kt_per - 1) / kt_per;
+  p.use_atomics = p.splitk > 1;
+  p.accumulate = accumulate;
+  if (p.use_atomics && !accumulate) {
+    hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)No * sizeof(float), (size_t)Mo, s);
+    if (e != hipSuccess) DEMO_FAIL(-2, "demo_gemm_tn_bf16: memset failed: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3((unsigned)tiles, (unsigned)p.splitk), dim3(256), 0, s, p);
+  DEMO_LAUNCH_CHECK("demo_gemm_tn_bf16");
+  return 0;
+}

@@ -63,7 +63,7 @@ template <typename TDY>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ w, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dx,
-                                                            int accumulate_dx, float* __restrict__ dw,
+                                                            int accumulate_dx, bf16_t* __restrict__ dx_lp, float* __restrict__ dw,
                                                             float* __restrict__ db, int M, int D, int rows_per_block) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [2][D]
   float* s_dw = sm;
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
           o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
         }
         *reinterpret_cast<float4*>(dxr + c * 4) = o;
+        if (dx_lp) io<bf16_t>::st4(dx_lp + (int64_t)row * D + c * 4, o);   // bf16 copy = A operand of the next backward GEMM
       }
     }
   }
@@ -202,8 +203,8 @@ extern "C" int demo_layernorm_fwd(const float* x, const float* w, const float* b
 }
 
 extern "C" int demo_layernorm_bwd(const void* dy, int32_t dtDy, const float* x, const float* w, const float* mean,
-                                  const float* rstd, float* dx, int32_t accumulate_dx, float* dw, float* db, int32_t M,
-                                  int32_t D, void* stream) {
+                                  const float* rstd, float* dx, int32_t accumulate_dx, void* dx_bf16, float* dw, float* db,
+                                  int32_t M, int32_t D, void* stream) {
   DEMO_REQUIRE(D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "demo_layernorm_bwd: D=%d unsupported", D);
   hipStream_t s = (hipStream_t)stream;
   const int rows_per_block = 64;
@@ -211,10 +212,10 @@ extern "C" int demo_layernorm_bwd(const void* dy, int32_t dtDy, const float* x, 
   const size_t shm = 2 * (size_t)D * sizeof(float);
   if (dtDy == DEMO_BF16)
     hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, grid, dim3(256), shm, s, (const bf16_t*)dy, x, w, mean, rstd, dx,
-                       accumulate_dx, dw, db, M, D, rows_per_block);
+                       accumulate_dx, (bf16_t*)dx_bf16, dw, db, M, D, rows_per_block);
   else
     hipLaunchKernelGGL(layernorm_bwd_kernel<float>, grid, dim3(256), shm, s, (const float*)dy, x, w, mean, rstd, dx,
-                       accumulate_dx, dw, db, M, D, rows_per_block);
+                       accumulate_dx, (bf16_t*)dx_bf16, dw, db, M, D, rows_per_block);
   DEMO_LAUNCH_CHECK("demo_layernorm_bwd");
   return 0;
 }

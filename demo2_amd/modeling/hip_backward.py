@@ -1,0 +1,424 @@
+"""Backward kernel schedule of the hot path and the training-step driver.
+
+The forward in training mode (`train_forward`) records every activation on a Tape (HBM is plentiful: nothing is
+recomputed) and returns the reference's output tuple through ONE autograd boundary node; when the loss calls
+.backward(), `model_backward` replays the schedule in reverse through libdemo_hip.so.  Parameter gradients are
+ACCUMULATED straight into the model's flat fp32 gradient buffer (every p.grad is a view of it), so a data-parallel
+run reduces a few large contiguous slices with RCCL while the remaining backward kernels are still running.
+
+Gradient formulas follow the forward definitions cited in hip_forward.py; every step is checked against torch
+autograd of the CPU oracle in tests/test_gpu_train.py.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from .. import ops
+from ..ops import ACT_GELU, ACT_QUICKGELU
+from . import hip_forward as HF
+from .hip_forward import BRANCHES, NC_PAD
+
+
+# ------------------------------------------------------------------------------------------------ autograd boundary
+class _Boundary(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, tape, anchor, *outs):
+        ctx.model, ctx.tape = model, tape
+        return tuple(o.detach() for o in outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        model_backward(ctx.model, ctx.tape, list(gouts))
+        ctx.tape = None
+        return (None, None, None) + tuple(None for _ in gouts)
+
+
+def train_forward(m, imgs: List[torch.Tensor], cam: Optional[torch.Tensor]):
+    """Training-mode forward: the reference's return tuple (engine/processor.py:80-97 pairing), differentiable."""
+    m.prepare_grads()
+    tape = HF.Tape()
+    B = imgs[0].shape[0]
+    tape.d["B"] = B
+    T = m.compute_dtype
+    tokens = HF.trunk_forward(m, imgs, cam, T, (), tape)
+    ori = HF.pife_forward(m, tokens, B, tape)
+    moe = None
+    if m.HDM:
+        feats = HF.hdm_forward(m, tokens, ori, B, True, tape)
+        moe = HF.atmoe_forward(m, feats, B, True, tape) if m.ATM else feats.view(B, -1)
+    outs = m._train_outputs(ori, moe, tape)
+    tens = [o for o in outs if torch.is_tensor(o)]
+    tape.d["n_out"] = len(tens)
+    wrapped = list(_Boundary.apply(m, tape, m.anchor(), *tens))
+    return tuple(wrapped.pop(0) if torch.is_tensor(o) else o for o in outs)
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def _ones(m, n):
+    key = ("ones", (n,), torch.float32)
+    if key not in m._ws or m._ws[key].device != m.ptab.flat.device:
+        m._ws[key] = torch.ones(n, device=m.ptab.flat.device, dtype=torch.float32)
+    return m._ws[key]
+
+
+def _bias_grad(m, src, src_off, N, Bn, src_ld, G, g_off, batch=(1, 1), sSrc=(0, 0), sG=(0, 0)):
+    """G[g_off + z*sG + n] += sum_b src[src_off + z*sSrc + b*src_ld + n]  (column sums as a 1 x Bn times Bn x N product,
+    so that strided / grouped bias blocks of the flat gradient buffer are reached without scatter kernels)."""
+    ones = _ones(m, Bn)
+    ops.gemm_raw(ones, src, G, 1, N, Bn, Bn, 1, 1, src_ld, N, b_off=src_off, c_off=g_off, batch1=batch[0], batch2=batch[1],
+                 sA=(0, 0), sB=sSrc, sC=sG, accumulate=True)
+
+
+def _head_backward(m, tape, tag, dscore, dx):
+    """classifier(bottleneck(x)) backward; the feature gradient is accumulated into dx (B, F)."""
+    P, G = m.ptab, m.grad_buffer()
+    h = tape.d["head_" + tag]
+    x, xb, (sm, si), bn, cls = h["x"], h["xb"], h["stats"], h["bn"], h["cls"]
+    W = P.f(cls + ".weight")                                      # (classes, F)
+    ops.gemm_tn(dscore, xb, G, out_off=P.off(cls + ".weight"), ldc=W.shape[1], accumulate=True)
+    dxb = ops.gemm(dscore, W.t())                                 # (B, F)
+    if m._frozen is None:
+        m._frozen = {n for n, p in m.named_parameters() if not p.requires_grad}
+    db = None if (bn + ".bias") in m._frozen else G[P.off(bn + ".bias"):]     # BNNeck bias is frozen (make_model.py:137,177)
+    ops.batchnorm_bwd(dxb, x, P.f(bn + ".weight"), None, sm, si, G[P.off(bn + ".weight"):], db, dx=dx, accumulate_dx=True)
+
+
+def model_backward(m, tape, gouts):
+    _model_backward(m, tape, gouts)
+    if m.grad_sync is not None:
+        m.grad_sync.backward_done()
+
+
+def _zeros_like_or(gr, ref):
+    return torch.zeros_like(ref) if gr is None else gr.contiguous().float().clone()
+
+
+def _model_backward(m, tape, gouts):
+    g = m.geom
+    B, C = tape.d["B"], g.feat_dim
+    gi = iter(gouts)
+    d_moe = None
+    has_moe = m.HDM
+    # ---- heads -----------------------------------------------------------------------------------------------
+    if has_moe:
+        ds, dfe = next(gi), next(gi)
+        d_moe = _zeros_like_or(dfe, tape.d["head_moe"]["x"])
+        if ds is not None:
+            _head_backward(m, tape, "moe", ds.contiguous().float(), d_moe)
+    if m.direct:
+        ds, dfe = next(gi), next(gi)
+        d_ori = _zeros_like_or(dfe, tape.d["head_ori"]["x"])
+        if ds is not None:
+            _head_backward(m, tape, "ori", ds.contiguous().float(), d_ori)
+    else:
+        d_ori = torch.zeros(B, 3 * C, device=tape.d["head_r"]["x"].device, dtype=torch.float32)
+        for i, s in enumerate("rnt"):
+            ds, dfe = next(gi), next(gi)
+            dgi = _zeros_like_or(dfe, tape.d["head_" + s]["x"])
+            if ds is not None:
+                _head_backward(m, tape, s, ds.contiguous().float(), dgi)
+            d_ori[:, i * C:(i + 1) * C] = dgi
+    dtok = None
+    if has_moe:
+        dfeats = atmoe_backward(m, tape, d_moe, B) if m.ATM else d_moe.view(B, 7, C)
+        dtok = hdm_backward(m, tape, dfeats, d_ori, B)
+    dtokens = pife_backward(m, tape, d_ori, dtok, B)
+    trunk_backward(m, tape, dtokens)
+
+
+# ------------------------------------------------------------------------------------------------ ATMoE
+def atmoe_backward(m, tape, d_moe, B):
+    g, P, G, t = m.geom, m.ptab, m.grad_buffer(), tape.d
+    C, H = g.feat_dim, g.moe_head
+    d = C // H
+    dev = d_moe.device
+    feats = t["feats"]
+    gk = "generalFusion.moe.gating_network.gate."
+    e0 = "generalFusion.moe.experts.0.expertHead.0.mlp."
+    e1 = "generalFusion.moe.experts.0.expertHead.1.mlp."
+    es = P.off(e1 + "0.weight") - P.off(e0 + "0.weight")
+    # BN(+gate) of the experts
+    dgate = torch.zeros(B, H, 7, device=dev, dtype=torch.float32)
+    sm2, si2 = t["at_bn2"]
+    dy = ops.batchnorm_bwd(d_moe, t["at_y"], P.f(e0 + "2.weight"), P.f(e0 + "2.bias"), sm2, si2, G[P.off(e0 + "2.weight"):],
+                           G[P.off(e0 + "2.bias"):], group=(d, H, 7, es), gate=t["at_gates"], dgate=dgate)
+    dypre = ops.act_bwd(dy, t["at_ypre"], ACT_QUICKGELU)
+    # expert Linear(d,d): dW[h,j] += dypre_chunk^T feats_chunk ; db += colsum ; dfeats_chunk = dypre_chunk W
+    ops.gemm_raw(dypre, feats, G, d, d, B, 1, 7 * C, 1, 7 * C, d, c_off=P.off(e0 + "0.weight"), batch1=H, batch2=7, sA=(d, C), sB=(d, C),
+                 sC=(7 * es, es), accumulate=True)
+    _bias_grad(m, dypre, 0, d, B, 7 * C, G, P.off(e0 + "0.bias"), batch=(H, 7), sSrc=(d, C), sG=(7 * es, es))
+    dfeats = torch.empty(B, 7, C, device=dev, dtype=torch.float32)
+    ops.gemm_raw(dypre, P.flat, dfeats, B, d, d, 7 * C, 1, 1, d, 7 * C, b_off=P.off(e0 + "0.weight"), batch1=H, batch2=7, sA=(d, C),
+                 sB=(7 * es, es), sC=(d, C))
+    # gate: softmax -> q,k projections -> BN -> QuickGELU -> Linear(7C, C)
+    dq, dk = ops.atmoe_gate_softmax_bwd(dgate, t["at_gates"], t["at_q"], t["at_k"], B, C, H)
+    ops.gemm_tn(dq, t["at_x2"], G, out_off=P.off(gk + "q_.weight"), ldc=C, accumulate=True)
+    dx2 = ops.gemm(dq, P.f(gk + "q_.weight").t())
+    ops.gemm_tn(dk, feats.view(B * 7, C), G, out_off=P.off(gk + "k_.weight"), ldc=C, accumulate=True)
+    ops.gemm(dk, P.f(gk + "k_.weight").t(), out=dfeats.view(B * 7, C), accumulate=True)
+    sm1, si1 = t["at_bn1"]
+    dx1 = ops.batchnorm_bwd(dx2, t["at_x1"], P.f(gk + "linear_re.2.weight"), None, sm1, si1, G[P.off(gk + "linear_re.2.weight"):],
+                            G[P.off(gk + "linear_re.2.bias"):])
+    dx1pre = ops.act_bwd(dx1, t["at_x1pre"], ACT_QUICKGELU)
+    ops.gemm_tn(dx1pre, feats.view(B, 7 * C), G, out_off=P.off(gk + "linear_re.0.weight"), ldc=7 * C, accumulate=True)
+    ops.colsum(dx1pre, out=G[P.off(gk + "linear_re.0.bias"):P.off(gk + "linear_re.0.bias") + C], accumulate=True)
+    ops.gemm(dx1pre, P.f(gk + "linear_re.0.weight").t(), out=dfeats.view(B, 7 * C), accumulate=True)
+    return dfeats
+
+
+# ------------------------------------------------------------------------------------------------ HDM
+def hdm_backward(m, tape, dfeats, d_ori, B):
+    """-> dtok (3B*L, C) fp32: gradient w.r.t. the HDM token streams (rows 0 already routed into d_ori)."""
+    g, P, G, t = m.geom, m.ptab, m.grad_buffer(), tape.d
+    L, C, Hh = g.n_patches + 1, g.feat_dim, g.hdm_heads
+    dev = dfeats.device
+    f = "generalFusion."
+    tokens = t["tokens"]
+    T = tokens.dtype
+    sw = P.stride(*[f + b + ".in_proj_weight" for b in BRANCHES])
+    sb = P.stride(*[f + b + ".in_proj_bias" for b in BRANCHES])
+    sow = P.stride(*[f + b + ".out_proj.weight" for b in BRANCHES])
+    sob = P.stride(*[f + b + ".out_proj.bias" for b in BRANCHES])
+    stok = P.stride(*[f + b + "_token" for b in BRANCHES])
+    o_w, o_b = P.off(f + "r.in_proj_weight"), P.off(f + "r.in_proj_bias")
+    o_ow, o_ob = P.off(f + "r.out_proj.weight"), P.off(f + "r.out_proj.bias")
+    dfeats = dfeats.contiguous()
+    o = t["hdm_o"]
+    # out_proj
+    ops.gemm_raw(dfeats, o, G, C, C, B, 1, 7 * C, 1, 7 * C, C, c_off=o_ow, batch1=7, sA=(C, 0), sB=(C, 0), sC=(sow, 0), accumulate=True)
+    _bias_grad(m, dfeats, 0, C, B, 7 * C, G, o_ob, batch=(7, 1), sSrc=(C, 0), sG=(sob, 0))
+    do = torch.empty(B, 7, C, device=dev, dtype=torch.float32)
+    ops.gemm_raw(dfeats, P.flat, do, B, C, C, 7 * C, 1, 1, C, 7 * C, b_off=o_ow, batch1=7, sA=(C, 0), sB=(sow, 0), sC=(C, 0))
+    # per-head value projection
+    pooled, psum, pdrop = t["hdm_pooled"], t["hdm_psum"], t["hdm_pdrop"]
+    ops.gemm_raw(do, pooled, G, 64, C, B, 1, 7 * C, 1, 7 * Hh * C, C, c_off=o_w + 2 * C * C, batch1=7, batch2=Hh, sA=(C, 64), sB=(Hh * C, C),
+                 sC=(sw, 64 * C), accumulate=True)
+    dpsum = None
+    if pdrop > 0:
+        dpsum = torch.zeros(B, 7, Hh, device=dev, dtype=torch.float32)
+        ops.hdm_vbias_bwd(do, P.flat, o_b + 2 * C, sb, psum, G, dpsum, B, C, Hh)
+    else:
+        _bias_grad(m, do, 0, C, B, 7 * C, G, o_b + 2 * C, batch=(7, 1), sSrc=(C, 0), sG=(sb, 0))
+    dpooled = torch.empty(B, 7, Hh, C, device=dev, dtype=torch.float32)
+    ops.gemm_raw(do, P.flat, dpooled, B, C, 64, 7 * C, 1, 1, C, 7 * Hh * C, b_off=o_w + 2 * C * C, batch1=7, batch2=Hh, sA=(C, 64),
+                 sB=(sw, 64 * C), sC=(Hh * C, C))
+    # softmax + pooling
+    dS, dtok = ops.hdm_softmax_pool_bwd(dpooled, dpsum, t["hdm_probs"], tokens, pooled, psum, B, L, C, Hh, NC_PAD, pdrop, t["hdm_seed"])
+    # scores S = tokens U^T
+    U = t["hdm_U"]
+    if T == torch.bfloat16:
+        dS_lp = ops.cast_f32_bf16(dS.view(-1), torch.empty(dS.numel(), device=dev, dtype=torch.bfloat16)).view_as(dS)
+        Ut = ops.transpose(U)
+    else:
+        dS_lp, Ut = dS, U.t()
+    dU = torch.empty(NC_PAD, C, device=dev, dtype=torch.float32)
+    ops.gemm_tn(dS_lp, tokens, dU, accumulate=False)
+    ops.gemm(dS_lp, Ut, out=dtok, accumulate=True)
+    # U[(br,h), :] = dh^-0.5 * Wk_h^T q_h ;  q = Wq tok + bq
+    q = t["hdm_q"]
+    scale = 64 ** -0.5
+    dq = torch.empty(7, C, device=dev, dtype=torch.float32)
+    ops.gemm_raw(dU, P.flat, dq, 1, 64, C, C, 1, C, 1, C, b_off=o_w + C * C, alpha=scale, batch1=7, batch2=Hh, sA=(Hh * C, C), sB=(sw, 64 * C),
+                 sC=(C, 64))
+    ops.gemm_raw(q, dU, G, 64, C, 1, 1, 1, 1, 1, C, c_off=o_w + C * C, alpha=scale, batch1=7, batch2=Hh, sA=(C, 64), sB=(Hh * C, C),
+                 sC=(sw, 64 * C), accumulate=True)
+    ops.gemm_raw(dq, P.flat, G, C, C, 1, 1, 1, 1, 1, C, b_off=P.off(f + "r_token"), c_off=o_w, batch1=7, sA=(C, 0), sB=(stok, 0), sC=(sw, 0),
+                 accumulate=True)
+    _bias_grad(m, dq, 0, C, 1, C, G, o_b, batch=(7, 1), sSrc=(C, 0), sG=(sb, 0))
+    ops.gemm_raw(dq, P.flat, G, 1, C, C, C, 1, 1, C, C, b_off=o_w, c_off=P.off(f + "r_token"), batch1=7, sA=(C, 0), sB=(sw, 0), sC=(stok, 0),
+                 accumulate=True)
+    # row 0 of every stream is the (PIFE) global feature: route its gradient into d_ori
+    for i in range(3):
+        ops.token0_grad(dtok[i * B * L:(i + 1) * B * L], d_ori, i * C, 3 * C, B, L)
+    return dtok
+
+
+# ------------------------------------------------------------------------------------------------ PIFE
+def pife_backward(m, tape, d_ori, dtok, B):
+    """-> dtokens (3B*L, C) in the compute dtype: gradient w.r.t. the trunk output."""
+    g, P, G, t = m.geom, m.ptab, m.grad_buffer(), tape.d
+    L, C = g.n_patches + 1, g.feat_dim
+    dev = d_ori.device
+    T = m.compute_dtype
+    dtokens = torch.empty(3 * B * L, C, device=dev, dtype=T)
+    if not g.global_local:
+        for i in range(3):
+            sl = slice(i * B * L, (i + 1) * B * L)
+            ops.tokens_grad(None if dtok is None else dtok[sl], d_ori, i * C, 3 * C, None, 0, 0, False, dtokens[sl], B, L)
+        return dtokens
+    dpre = ops.act_bwd(d_ori, t["pife_pre"], ACT_QUICKGELU)                       # (B, 3C)
+    zl, z = t["pife_zl"], t["pife_z"]
+    s_w = P.stride("rgb_reduce.1.weight", "nir_reduce.1.weight", "tir_reduce.1.weight")
+    s_b = P.stride("rgb_reduce.1.bias", "nir_reduce.1.bias", "tir_reduce.1.bias")
+    o_w, o_b = P.off("rgb_reduce.1.weight"), P.off("rgb_reduce.1.bias")
+    ops.gemm_raw(dpre, zl, G, C, 2 * C, B, 1, 3 * C, 1, 2 * C, 2 * C, c_off=o_w, batch1=3, sA=(C, 0), sB=(B * 2 * C, 0), sC=(s_w, 0),
+                 accumulate=True)
+    _bias_grad(m, dpre, 0, C, B, 3 * C, G, o_b, batch=(3, 1), sSrc=(C, 0), sG=(s_b, 0))
+    dzl = torch.empty(3 * B, 2 * C, device=dev, dtype=torch.float32)
+    ops.gemm_raw(dpre, P.flat, dzl, B, 2 * C, C, 3 * C, 1, 1, 2 * C, 2 * C, b_off=o_w, batch1=3, sA=(C, 0), sB=(s_w, 0), sC=(B * 2 * C, 0))
+    dz = torch.empty(3 * B, 2 * C, device=dev, dtype=torch.float32)
+    for i, name in enumerate(("rgb_reduce", "nir_reduce", "tir_reduce")):
+        mean, rstd = t["pife_stats"][i]
+        sl = slice(i * B, (i + 1) * B)
+        ops.layernorm_bwd(dzl[sl], z[sl], P.f(name + ".0.weight"), mean, rstd, dx=dz[sl], dw=G[P.off(name + ".0.weight"):],
+                          db=G[P.off(name + ".0.bias"):])
+    for i in range(3):
+        sl = slice(i * B * L, (i + 1) * B * L)
+        dzi = dz[i * B:(i + 1) * B]
+        ops.tokens_grad(None if dtok is None else dtok[sl], dzi, 0, 2 * C, dzi, C, 2 * C, False, dtokens[sl], B, L)
+    return dtokens
+
+
+# ------------------------------------------------------------------------------------------------ trunk
+def trunk_backward(m, tape, dtokens):
+    g, P, G, t = m.geom, m.ptab, m.grad_buffer(), tape.d
+    B = t["B"]
+    Bn, np_, L, W = 3 * B, g.n_patches, g.n_patches + 1, g.width
+    T = m.compute_dtype
+    dev = dtokens.device
+    lp = T == torch.bfloat16
+    act = ACT_QUICKGELU if g.arch == "clip" else ACT_GELU
+    sync = m.grad_sync
+
+    def gw(name):
+        return G[P.off(name):]
+
+    # ---- final projection + LayerNorm --------------------------------------------------------------------------
+    if g.arch == "clip":
+        y = t["y"]
+        ops.gemm_tn(y, dtokens, G, out_off=P.off(g.k_proj), ldc=g.feat_dim, accumulate=True)      # dproj (W, C) = y^T dtokens
+        dy = ops.gemm(dtokens, P.w(g.k_proj, T))                                                   # (3BL, W) = dtokens proj^T
+    else:
+        dy = dtokens
+    dx = torch.empty(Bn * L, W, device=dev, dtype=torch.float32)
+    dxb = torch.empty(Bn * L, W, device=dev, dtype=torch.bfloat16) if lp else None
+    ops.layernorm_bwd(dy, t["x_final"], P.f(g.k_lnpost + ".weight"), t["meanf"], t["rstdf"], dx=dx, dw=gw(g.k_lnpost + ".weight"),
+                      db=gw(g.k_lnpost + ".bias"), dx_lp=dxb)
+    if sync is not None:
+        sync.tail_ready()
+    # ---- blocks in reverse ---------------------------------------------------------------------------------------------
+    for i in reversed(range(g.layers)):
+        k, s = g.block_keys(i), tape.blocks[i]
+        d_res = dxb if lp else dx                                   # gradient of the block output, GEMM operand dtype
+        # x2 = x1 + fc2(u)
+        ops.gemm_tn(d_res, s["u"], G, out_off=P.off(k["fc2_w"]), ldc=4 * W, accumulate=True)
+        ops.colsum(d_res, out=G[P.off(k["fc2_b"]):P.off(k["fc2_b"]) + W], accumulate=True)
+        dpre = ops.gemm(d_res, P.wt(k["fc2_w"], T), act_grad_pre=s["pre"], act_grad_kind=act)      # (M, 4W) = (dx W2) * act'(pre)
+        # u = act(fc1(h2))
+        ops.gemm_tn(dpre, s["h2"], G, out_off=P.off(k["fc1_w"]), ldc=W, accumulate=True)
+        ops.colsum(dpre, out=G[P.off(k["fc1_b"]):P.off(k["fc1_b"]) + 4 * W], accumulate=True)
+        dh2 = ops.gemm(dpre, P.wt(k["fc1_w"], T))                                                  # (M, W)
+        ops.layernorm_bwd(dh2, s["x1"], P.f(k["ln2"] + ".weight"), s["mean2"], s["rstd2"], dx=dx, accumulate_dx=True,
+                          dw=gw(k["ln2"] + ".weight"), db=gw(k["ln2"] + ".bias"), dx_lp=dxb)
+        d_res = dxb if lp else dx
+        # x1 = x + out_proj(a)
+        ops.gemm_tn(d_res, s["a"], G, out_off=P.off(k["proj_w"]), ldc=W, accumulate=True)
+        ops.colsum(d_res, out=G[P.off(k["proj_b"]):P.off(k["proj_b"]) + W], accumulate=True)
+        da = ops.gemm(d_res, P.wt(k["proj_w"], T))                                                 # (M, W)
+        dqkv = ops.attention_bwd(s["qkv"], s["a"], da, s["lse"], Bn, L, g.heads)                   # (M, 3W)
+        ops.gemm_tn(dqkv, s["h1"], G, out_off=P.off(k["qkv_w"]), ldc=W, accumulate=True)
+        ops.colsum(dqkv, out=G[P.off(k["qkv_b"]):P.off(k["qkv_b"]) + 3 * W], accumulate=True)
+        dh1 = ops.gemm(dqkv, P.wt(k["qkv_w"], T))                                                  # (M, W)
+        ops.layernorm_bwd(dh1, s["x"], P.f(k["ln1"] + ".weight"), s["mean1"], s["rstd1"], dx=dx, accumulate_dx=True,
+                          dw=gw(k["ln1"] + ".weight"), db=gw(k["ln1"] + ".bias"), dx_lp=dxb)
+        tape.blocks[i] = None                                       # release the activations of this block
+        if sync is not None:
+            sync.block_ready(i)
+    # ---- embedding ----------------------------------------------------------------------------------------------------
+    if g.k_lnpre:
+        dpre = ops.layernorm_bwd(dx, t["emb_pre"], P.f(g.k_lnpre + ".weight"), t["emb_mean"], t["emb_rstd"], dw=gw(g.k_lnpre + ".weight"),
+                                 db=gw(g.k_lnpre + ".bias"))
+    else:
+        dpre = dx
+    dpatch = ops.embed_tokens_bwd(dpre, t["cam3"], g.sie_coe, g.cam_all_tokens, T, gw(g.k_cls), gw(g.k_pos),
+                                  gw(g.cam_embed) if g.cam_embed else None, Bn, np_)
+    ops.gemm_tn(dpatch, t["cols"], G, out_off=P.off(g.k_conv), ldc=3 * g.patch * g.patch, accumulate=True)
+    if g.k_conv_bias:
+        ops.colsum(dpatch, out=G[P.off(g.k_conv_bias):P.off(g.k_conv_bias) + W], accumulate=True)
+
+
+# ------------------------------------------------------------------------------------------------ training step driver
+def label_smooth_xent(logits, target, eps=0.1):
+    """CrossEntropyLabelSmooth (layers/softmax_loss.py:23-34)."""
+    logp = torch.log_softmax(logits.float(), 1)
+    K = logits.shape[1]
+    t = torch.full_like(logp, eps / K).scatter_(1, target[:, None], 1 - eps + eps / K)
+    return (-t * logp).mean(0).sum()
+
+
+def triplet_soft_margin(feat, labels):
+    """TripletLoss() without margin: batch-hard mining + SoftMarginLoss (layers/triplet_loss.py:51-135)."""
+    feat = feat.float()
+    sq = (feat ** 2).sum(1, keepdim=True)
+    dist = (sq + sq.t() - 2 * feat @ feat.t()).clamp(min=1e-12).sqrt()
+    same = labels[:, None] == labels[None, :]
+    d_ap = torch.where(same, dist, dist.new_full((), float("-inf"))).max(1).values
+    d_an = torch.where(~same, dist, dist.new_full((), float("inf"))).min(1).values
+    return torch.nn.functional.softplus(-(d_an - d_ap)).mean()
+
+
+def make_loss_fn(cfg):
+    """layers/make_loss.py:37-55 ('softmax_triplet' sampler, label smoothing on, soft-margin triplet)."""
+    idw, trw = float(cfg.MODEL.ID_LOSS_WEIGHT), float(cfg.MODEL.TRIPLET_LOSS_WEIGHT)
+
+    def loss_fn(score, feat, target, target_cam=None):
+        return idw * label_smooth_xent(score, target) + trw * triplet_soft_margin(feat, target)
+    return loss_fn
+
+
+def total_loss(outputs, target, loss_fn):
+    """Pairing rule of engine/processor.py:80-97."""
+    n = len(outputs) - (len(outputs) % 2)
+    loss = 0
+    for i in range(0, n, 2):
+        loss = loss + loss_fn(outputs[i], outputs[i + 1], target)
+    if len(outputs) % 2 == 1:
+        loss = loss + outputs[-1]
+    return loss
+
+
+class TrainStep:
+    """One optimisation step of the reference's do_train loop (engine/processor.py:57-104) on resident tensors:
+    forward, loss, backward (with in-backward RCCL gradient reduction when world > 1), fused flat Adam."""
+
+    def __init__(self, model, cfg, world=1, lr=None, optimizer=True):
+        from ..dist import GradSync
+        self.model, self.cfg = model, cfg
+        self.loss_fn = make_loss_fn(cfg)
+        self.lr = float(cfg.SOLVER.BASE_LR if lr is None else lr)
+        self.wd = float(cfg.SOLVER.WEIGHT_DECAY)
+        self.optimizer = optimizer
+        self.t = 0
+        model.grad_sync = GradSync(model) if world > 1 else None
+        flat = model.ptab.flat
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+
+    def step(self, x, target, cam):
+        model = self.model
+        out = model(x, label=target, cam_label=cam)
+        loss = total_loss(out, target, self.loss_fn)
+        loss.backward()
+        if self.optimizer:
+            self.t += 1
+            model.adam_step(self.m, self.v, self.lr, 0.9, 0.999, 1e-8, self.wd, self.t)
+        return loss
+
+
+def train_step_smoke(m, xd, cam):
+    """One fwd+bwd+Adam step on the smoke batch; checks that the loss is finite and the parameters moved."""
+    from ..config import get_defaults
+    m.train()
+    B = cam.shape[0]
+    target = torch.arange(B, device=cam.device) // 2
+    ts = TrainStep(m, m.cfg, 1)
+    before = m.ptab.flat.clone()
+    loss = ts.step(xd, target, cam)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss).item(), loss
+    moved = (m.ptab.flat - before).abs().max().item()
+    print(f"smoke: train step loss = {loss.item():.4f}, max |dparam| = {moved:.2e}")
+    assert moved > 0
+    m.eval()

@@ -62,6 +62,13 @@ class FlatTable:
         """2-D parameter transposed and contiguous, dtype T (refreshed with the shadow)."""
         return self.extra[(name, T)]
 
+    def wt(self, name: str, T: torch.dtype) -> torch.Tensor:
+        """W^T of a 2-D weight for the backward product dX = dY W: a strided view in fp32 mode (generic kernel), a
+        contiguous bf16 copy in bf16 mode (MFMA kernel)."""
+        if T == torch.float32:
+            return self.f(name).t()
+        return self.extra[("t", name)]
+
     def stride(self, *names) -> int:
         offs = [self.off(n) for n in names]
         d = {b - a for a, b in zip(offs, offs[1:])}
@@ -137,6 +144,9 @@ class DeMo(_Holder):
         self._ws: Dict[str, torch.Tensor] = {}
         self._seed = 0x5EED
         self._plist = None
+        self._anchor = None
+        self._frozen = None
+        self.grad_sync = None            # set by demo2_amd.dist.GradSync for data-parallel runs
         self.geom = self._make_geometry(cfg)
         self._flatten()
 
@@ -266,16 +276,56 @@ class DeMo(_Holder):
         """Compute-dtype copies of the weights (bf16 shadow for the MFMA GEMMs, transposed CLIP proj);
         one cast launch whenever any parameter changed in place (optimizer step, load_state_dict)."""
         P, T = self.ptab, self.compute_dtype
-        ver = self._param_version()
+        ver = (self._param_version(), bool(self.training), T)
         if P.shadow_version == ver and (T != torch.bfloat16 or P.shadow is not None):
             return
         if T == torch.bfloat16:
             if P.shadow is None:
                 P.shadow = torch.empty(P.flat.numel(), device=P.flat.device, dtype=torch.bfloat16)
             ops.cast_f32_bf16(P.flat, P.shadow)
-        if self.geom.k_proj:
-            P.extra[(self.geom.k_proj, T)] = ops.transpose(P.w(self.geom.k_proj, T))
+        self._refresh_derived()
         P.shadow_version = ver
+
+    def _refresh_derived(self):
+        """Transposed weight copies: CLIP proj^T for the forward; in bf16 training mode also W^T of every trunk Linear,
+        so that dX = dY W runs on the K-contiguous MFMA kernel (weights are small: ~170 MB, one pass per step)."""
+        P, T, g = self.ptab, self.compute_dtype, self.geom
+        if g.k_proj:
+            dst = P.extra.get((g.k_proj, T))
+            P.extra[(g.k_proj, T)] = ops.transpose(P.w(g.k_proj, T), dst)
+        if self.training and T == torch.bfloat16:
+            for i in range(g.layers):
+                k = g.block_keys(i)
+                for name in (k["qkv_w"], k["proj_w"], k["fc1_w"], k["fc2_w"]):
+                    P.extra[("t", name)] = ops.transpose(P.w(name, T), P.extra.get(("t", name)))
+
+    def anchor(self) -> torch.Tensor:
+        """1-element leaf that ties the kernel schedule into autograd (its own gradient is never produced)."""
+        dev = self.ptab.flat.device
+        if self._anchor is None or self._anchor.device != dev:
+            self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+        return self._anchor
+
+    def prepare_grads(self):
+        """Make every p.grad a view of the flat gradient buffer.  optimizer.zero_grad() (set_to_none) leaves None
+        gradients: that means 'zero', so the flat buffer is cleared and re-attached; existing views are accumulated into."""
+        if self._plist is None:
+            self._plist = [p for p in self.parameters()]
+        sentinel = next(p for p in self._plist if p.requires_grad)
+        gflat = self.grad_buffer()
+        lo, hi = gflat.data_ptr(), gflat.data_ptr() + 4 * gflat.numel()
+        if sentinel.grad is None or not (lo <= sentinel.grad.data_ptr() < hi):
+            self.attach_grads(zero=True)
+
+    def adam_step(self, m, v, lr, beta1, beta2, eps, weight_decay, t):
+        """Fused flat Adam over (flat params, flat grads); also refreshes the bf16 shadow and clears the gradients."""
+        P = self.ptab
+        lp = self.compute_dtype == torch.bfloat16
+        if lp and P.shadow is None:
+            P.shadow = torch.empty(P.flat.numel(), device=P.flat.device, dtype=torch.bfloat16)
+        ops.adam_step(P.flat, self.grad_buffer(), m, v, P.shadow if lp else None, lr, beta1, beta2, eps, weight_decay, t, zero_grad=True)
+        self._refresh_derived()
+        P.shadow_version = (self._param_version(), bool(self.training), self.compute_dtype)
 
     def workspace(self, name, shape, dtype, zero=False) -> torch.Tensor:
         key = (name, tuple(shape), dtype)

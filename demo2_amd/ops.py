@@ -220,16 +220,32 @@ def layernorm_fwd(x: Tensor, w: Tensor, b: Tensor, eps: float, out_dtype: torch.
 
 
 def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, dx: Optional[Tensor] = None,
-                  accumulate_dx: bool = False, dw: Optional[Tensor] = None, db: Optional[Tensor] = None):
-    """dx (fp32); dw/db are ACCUMULATED into the given fp32 buffers (zero them first if needed)."""
+                  accumulate_dx: bool = False, dw: Optional[Tensor] = None, db: Optional[Tensor] = None,
+                  dx_lp: Optional[Tensor] = None):
+    """dx (fp32); dw/db are ACCUMULATED into the given fp32 buffers (zero them first if needed);
+    dx_lp (optional bf16 tensor of x's shape) receives a bf16 copy of the final dx."""
     _req_cuda(dy, x)
     M, D = x.shape
     if dx is None:
         dx = torch.empty_like(x)
         accumulate_dx = False
+    if dx_lp is not None:
+        assert dx_lp.dtype == torch.bfloat16 and dx_lp.is_contiguous() and dx_lp.shape == x.shape
     check(_lib.load().demo_layernorm_bwd(dy.data_ptr(), dt_code(dy.dtype), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                         dx.data_ptr(), int(accumulate_dx), _ptr(dw), _ptr(db), M, D, _stream()), "demo_layernorm_bwd")
+                                         dx.data_ptr(), int(accumulate_dx), _ptr(dx_lp), _ptr(dw), _ptr(db), M, D, _stream()),
+          "demo_layernorm_bwd")
     return dx
+
+
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, shadow: Optional[Tensor], lr: float, beta1: float, beta2: float, eps: float,
+              weight_decay: float, step: int, zero_grad: bool = True):
+    """Fused flat Adam (torch.optim.Adam semantics, L2 weight decay folded into the gradient) over the flat parameter /
+    gradient buffers; optionally refreshes the bf16 weight shadow and zeroes the gradient in the same pass."""
+    _req_cuda(p, g, m, v)
+    n = p.numel()
+    assert g.numel() == n and m.numel() == n and v.numel() == n and (shadow is None or shadow.numel() == n)
+    check(_lib.load().demo_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(shadow), n, float(lr), float(beta1),
+                                     float(beta2), float(eps), float(weight_decay), int(step), int(zero_grad), _stream()), "demo_adam_step")
 
 
 def batchnorm_fwd(x: Tensor, w: Tensor, b: Tensor, running_mean: Tensor, running_var: Tensor, training: bool, momentum: float,
@@ -297,17 +313,125 @@ def get_token0(tokens: Tensor, out: Tensor, out_off: int, out_ld: int, Bn: int, 
 
 
 def hdm_softmax_pool(S: Tensor, tokens: Tensor, Bs: int, L: int, Cd: int, Hh: int, ldS: int, p_drop: float = 0.0, seed: int = 0,
-                     save_probs: bool = False):
+                     save_probs: bool = False, save_probs_post: bool = False):
+    """-> pooled (Bs,7,Hh,C), psum (Bs,7,Hh), probs (softmax BEFORE dropout) [, probs_post (after dropout)]"""
     _req_cuda(S, tokens)
     assert S.dtype == torch.float32 and S.shape == (3 * Bs * L, ldS) and S.is_contiguous() and ldS >= 7 * Hh
     assert tokens.is_contiguous() and tokens.numel() == 3 * Bs * L * Cd
     pooled = torch.empty(Bs, 7, Hh, Cd, device=S.device, dtype=torch.float32)
     psum = torch.empty(Bs, 7, Hh, device=S.device, dtype=torch.float32)
     probs = torch.empty(Bs, 7, Hh, 3 * L, device=S.device, dtype=torch.float32) if save_probs else None
+    post = torch.empty(Bs, 7, Hh, 3 * L, device=S.device, dtype=torch.float32) if save_probs_post else None
     check(_lib.load().demo_hdm_softmax_pool(S.data_ptr(), ldS, tokens.data_ptr(), dt_code(tokens.dtype), pooled.data_ptr(), psum.data_ptr(),
-                                            _ptr(probs), Bs, L, Cd, Hh, float(p_drop), int(seed) & (2 ** 64 - 1), _stream()),
+                                            _ptr(probs), _ptr(post), Bs, L, Cd, Hh, float(p_drop), int(seed) & (2 ** 64 - 1), _stream()),
           "demo_hdm_softmax_pool")
-    return pooled, psum, probs
+    return (pooled, psum, probs, post) if save_probs_post else (pooled, psum, probs)
+
+
+def hdm_softmax_pool_bwd(dpooled: Tensor, dpsum: Optional[Tensor], probs: Tensor, tokens: Tensor, pooled: Tensor, psum: Tensor,
+                         Bs: int, L: int, Cd: int, Hh: int, ldS: int, p_drop: float = 0.0, seed: int = 0):
+    """-> dS (3Bs*L, ldS) fp32, dtokens (3Bs*L, C) fp32"""
+    _req_cuda(dpooled, probs, tokens, pooled, psum)
+    dS = torch.empty(3 * Bs * L, ldS, device=tokens.device, dtype=torch.float32)
+    dtok = torch.empty(3 * Bs * L, Cd, device=tokens.device, dtype=torch.float32)
+    check(_lib.load().demo_hdm_softmax_pool_bwd(dpooled.data_ptr(), _ptr(dpsum), probs.data_ptr(), tokens.data_ptr(), dt_code(tokens.dtype),
+                                                pooled.data_ptr(), psum.data_ptr(), dS.data_ptr(), ldS, dtok.data_ptr(), Bs, L, Cd, Hh,
+                                                float(p_drop), int(seed) & (2 ** 64 - 1), _stream()), "demo_hdm_softmax_pool_bwd")
+    return dS, dtok
+
+
+def hdm_vbias_bwd(dy: Tensor, bias_base: Tensor, bias_off: int, bias_stride: int, psum: Tensor, dbias_base: Tensor, dpsum: Tensor,
+                  Bs: int, Cd: int, Hh: int):
+    _req_cuda(dy, bias_base, psum, dbias_base, dpsum)
+    check(_lib.load().demo_hdm_vbias_bwd(dy.data_ptr(), bias_base.data_ptr() + 4 * bias_off, bias_stride, psum.data_ptr(),
+                                         dbias_base.data_ptr() + 4 * bias_off, dpsum.data_ptr(), Bs, Cd, Hh, _stream()), "demo_hdm_vbias_bwd")
+
+
+def atmoe_gate_softmax_bwd(dgates: Tensor, gates: Tensor, q: Tensor, k: Tensor, Bs: int, Cd: int, H: int):
+    _req_cuda(dgates, gates, q, k)
+    dq, dk = torch.empty_like(q), torch.empty_like(k)
+    check(_lib.load().demo_atmoe_gate_softmax_bwd(dgates.data_ptr(), gates.data_ptr(), q.data_ptr(), k.data_ptr(), dq.data_ptr(),
+                                                  dk.data_ptr(), Bs, Cd, H, _stream()), "demo_atmoe_gate_softmax_bwd")
+    return dq, dk
+
+
+def gemm_tn(a: Tensor, b: Tensor, out: Tensor, out_off: int = 0, ldc: Optional[int] = None, alpha: float = 1.0, accumulate: bool = True):
+    """out_flat[out_off + m*ldc + n] (+)= alpha * sum_r a[r, m] * b[r, n]   (weight gradients: a = dY, b = X).
+    bf16 operands with 128-multiples take the MFMA kernel; everything else the generic strided kernel."""
+    _req_cuda(a, b, out)
+    R, Mo = a.shape
+    No = b.shape[1]
+    assert b.shape[0] == R and out.dtype == torch.float32
+    ldc = No if ldc is None else ldc
+    if (a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and Mo % 128 == 0 and No % 128 == 0 and a.stride(1) == 1
+            and b.stride(1) == 1 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
+        check(_lib.load().demo_gemm_tn_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr() + 4 * out_off, Mo, No, R, a.stride(0), b.stride(0), ldc,
+                                            float(alpha), int(accumulate), _stream()), "demo_gemm_tn_bf16")
+        return out
+    return gemm_raw(a, b, out, Mo, No, R, a.stride(1), a.stride(0), b.stride(1), b.stride(0), ldc, c_off=out_off, alpha=alpha,
+                    accumulate=accumulate)
+
+
+def attention_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, Bn: int, L: int, H: int) -> Tensor:
+    _req_cuda(qkv, out, dout, lse)
+    assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dout.dtype == qkv.dtype
+    dqkv = torch.empty_like(qkv)
+    check(_lib.load().demo_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), Bn, L, H, 64,
+                                         dt_code(qkv.dtype), _stream()), "demo_attention_bwd")
+    return dqkv
+
+
+def embed_tokens_bwd(dpre: Tensor, cam: Optional[Tensor], cam_scale: float, cam_all_tokens: bool, dpatch_dtype: torch.dtype,
+                     dcls: Tensor, dpos: Tensor, dcam: Optional[Tensor], Bn: int, n_patch: int) -> Tensor:
+    """dcls / dpos / dcam are accumulated into (fp32 views of the flat gradient buffer); returns dpatch (Bn*n_patch, W)."""
+    _req_cuda(dpre, dcls, dpos)
+    W = dpre.shape[1]
+    dpatch = torch.empty(Bn * n_patch, W, device=dpre.device, dtype=dpatch_dtype)
+    check(_lib.load().demo_embed_tokens_bwd(dpre.data_ptr(), _ptr(cam), float(cam_scale), int(cam_all_tokens), dpatch.data_ptr(),
+                                            dt_code(dpatch_dtype), dcls.data_ptr(), dpos.data_ptr(), _ptr(dcam), Bn, n_patch, W, _stream()),
+          "demo_embed_tokens_bwd")
+    return dpatch
+
+
+def act_bwd(dy: Tensor, pre: Tensor, kind: int, out: Optional[Tensor] = None) -> Tensor:
+    _req_cuda(dy, pre)
+    assert dy.dtype == torch.float32 and pre.dtype == torch.float32 and dy.is_contiguous() and pre.is_contiguous()
+    out = torch.empty_like(dy) if out is None else out
+    check(_lib.load().demo_act_bwd(dy.data_ptr(), pre.data_ptr(), kind, out.data_ptr(), dy.numel(), _stream()), "demo_act_bwd")
+    return out
+
+
+def batchnorm_bwd(dy: Tensor, x: Tensor, w: Tensor, b: Optional[Tensor], save_mean: Tensor, save_invstd: Tensor, dw: Optional[Tensor],
+                  db: Optional[Tensor], dx: Optional[Tensor] = None, accumulate_dx: bool = False, group=None, gate: Optional[Tensor] = None,
+                  dgate: Optional[Tensor] = None) -> Tensor:
+    """dw/db: fp32 tensors whose data_ptr is the (group) base; accumulated into.  group = (gsz, n_inner, n_outer, pstride)."""
+    _req_cuda(dy, x, w)
+    Bn, Fd = x.shape
+    assert dy.is_contiguous() and x.is_contiguous() and dy.dtype == torch.float32
+    if dx is None:
+        dx, accumulate_dx = torch.empty_like(x), False
+    gsz, ni, no, ps = group if group is not None else (0, 1, 1, 0)
+    check(_lib.load().demo_batchnorm_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), _ptr(b), save_mean.data_ptr(), save_invstd.data_ptr(),
+                                         dx.data_ptr(), int(accumulate_dx), _ptr(dw), _ptr(db), Bn, Fd, gsz, ni, no, ps, _ptr(gate), _ptr(dgate),
+                                         _stream()), "demo_batchnorm_bwd")
+    return dx
+
+
+def token0_grad(dtokens: Tensor, out: Tensor, out_off: int, out_ld: int, Bn: int, L: int):
+    _req_cuda(dtokens, out)
+    Cd = dtokens.shape[-1]
+    check(_lib.load().demo_token0_grad(dtokens.data_ptr(), out.data_ptr() + 4 * out_off, out_ld, Bn, L, Cd, _stream()), "demo_token0_grad")
+
+
+def tokens_grad(dtok: Optional[Tensor], dcls: Optional[Tensor], cls_off: int, cls_ld: int, dmean: Optional[Tensor], mean_off: int,
+                mean_ld: int, keep_row0: bool, out: Tensor, Bn: int, L: int):
+    _req_cuda(out)
+    Cd = out.shape[-1]
+    pc = None if dcls is None else dcls.data_ptr() + 4 * cls_off
+    pm = None if dmean is None else dmean.data_ptr() + 4 * mean_off
+    check(_lib.load().demo_tokens_grad(_ptr(dtok), pc, cls_ld, pm, mean_ld, int(keep_row0), out.data_ptr(), dt_code(out.dtype), Bn, L, Cd,
+                                       _stream()), "demo_tokens_grad")
+    return out
 
 
 def hdm_vbias(y: Tensor, bias_base: Tensor, bias_off: int, bias_stride: int, psum: Tensor, Bs: int, Cd: int, Hh: int):

@@ -98,9 +98,10 @@ int demo_embed_tokens(const void* patch, int32_t dt_patch, const float* cls, con
  * (clip/model.py:154-160; nn.LayerNorm in vit_pytorch.py:178,182,401; make_model.py:52) */
 int demo_layernorm_fwd(const float* x, const float* w, const float* b, float eps, void* y, int32_t dtY,
                        float* mean, float* rstd, int32_t M, int32_t D, void* stream);
-/* dx (fp32, optionally accumulated into) from dy (dtype dtDy); dw/db partial sums are reduced inside. */
+/* dx (fp32, optionally accumulated into: the residual-stream gradient) from dy (dtype dtDy); dw/db are accumulated into
+ * (atomics); dx_bf16 (optional) receives a bf16 copy of the final dx = the A operand of the next backward GEMM. */
 int demo_layernorm_bwd(const void* dy, int32_t dtDy, const float* x, const float* w, const float* mean, const float* rstd,
-                       float* dx, int32_t accumulate_dx, float* dw, float* db, int32_t M, int32_t D, void* stream);
+                       float* dx, int32_t accumulate_dx, void* dx_bf16, float* dw, float* db, int32_t M, int32_t D, void* stream);
 
 /* BatchNorm1d over x (Bn, F) fp32 (nn.BatchNorm1d at AttnMOE.py:30,53; make_model.py:136,176).
  * training!=0: batch statistics (biased var), running stats updated in place with `momentum`
@@ -137,7 +138,16 @@ int demo_get_token0(const void* tokens, int32_t dt, float* out, int64_t out_ld, 
  * counter RNG, p_drop), pooled[b,br,h,:] = sum_l p_l * tokens_l  -> fp32 (Bs,7,Hh,C);
  * psum[b,br,h] = sum_l p_l (== 1 without dropout); probs (optional) saved for backward. */
 int demo_hdm_softmax_pool(const float* S, int64_t ldS, const void* tokens, int32_t dt, float* pooled, float* psum, float* probs,
-                          int32_t Bs, int32_t L, int32_t C, int32_t Hh, float p_drop, uint64_t seed, void* stream);
+                          float* probs_post, int32_t Bs, int32_t L, int32_t C, int32_t Hh, float p_drop, uint64_t seed, void* stream);
+/* Backward of the above.  probs = the forward's softmax BEFORE dropout (Bs,7,Hh,3L); the dropout mask is regenerated
+ * from (seed, p_drop).  dS (3*Bs*L, ldS) fp32 is fully written (zeros in the columns of branches that do not attend a
+ * row's modality); dtokens (3*Bs*L, C) fp32 is fully written (row 0 of every image = gradient of the PIFE global). */
+int demo_hdm_softmax_pool_bwd(const float* dpooled, const float* dpsum, const float* probs, const void* tokens, int32_t dt,
+                              const float* pooled, const float* psum, float* dS, int64_t ldS, float* dtokens, int32_t Bs,
+                              int32_t L, int32_t C, int32_t Hh, float p_drop, uint64_t seed, void* stream);
+/* value-projection bias under dropout, backward: dbias[br*stride + c] += sum_b dy*psum ; dpsum[b,br,h] += sum_c dy*bias */
+int demo_hdm_vbias_bwd(const float* dy, const float* bias, int64_t bias_stride, const float* psum, float* dbias, float* dpsum,
+                       int32_t Bs, int32_t C, int32_t Hh, void* stream);
 /* y[b, br, h*dh + e] += bias[br][h*dh+e] * psum[b,br,h]   (value-projection bias under dropout) */
 int demo_hdm_vbias(float* y, const float* bias, int64_t bias_stride, const float* psum, int32_t Bs, int32_t C, int32_t Hh,
                    void* stream);
@@ -145,6 +155,40 @@ int demo_hdm_vbias(float* y, const float* bias, int64_t bias_stride, const float
 /* ---- ATMoE gate (AttnMOE.py:61-68) ----------------------------------------------------------- */
 /* gates[b,h,j] = softmax_j( q[b, h*d:(h+1)*d] . k[b, j, h*d:(h+1)*d] * d^-0.5 ) */
 int demo_atmoe_gate_softmax(const float* q, const float* k, float* gates, int32_t Bs, int32_t C, int32_t H, void* stream);
+int demo_atmoe_gate_softmax_bwd(const float* dgates, const float* gates, const float* q, const float* k, float* dq, float* dk,
+                                int32_t Bs, int32_t C, int32_t H, void* stream);
+
+/* ---- backward-only entry points ------------------------------------------------------------------------- */
+/* Weight-gradient GEMM, both operands reduction-major (rows = tokens, exactly as the forward left them):
+ * C[Mo,No] (+)= alpha * sum_r A[r,Mo] * B[r,No]; bf16 MFMA, split over the reduction with fp32 atomics.
+ * dW of every nn.Linear in the trunk: A = dY (rows,N), B = X (rows,K) -> C = dW (N,K) inside the flat grad buffer. */
+int demo_gemm_tn_bf16(const void* A, const void* B, float* C, int32_t Mo, int32_t No, int32_t Kr, int64_t lda, int64_t ldb,
+                      int64_t ldc, float alpha, int32_t accumulate, void* stream);
+/* Self-attention backward (same packing as demo_attention_fwd; lse from the forward): dqkv (Bn*L, 3D). */
+int demo_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int32_t Bn,
+                       int32_t L, int32_t H, int32_t dh, int32_t dt, void* stream);
+/* Adjoint of demo_embed_tokens w.r.t. its un-normalised sum `pre` (dpre fp32 (Bn*(1+np), W)):
+ * dpatch (dtype dt_patch) = rows 1.., dcls += sum_b row 0, dpos[t] += sum_b row t, dcam[cam[b]] += cam_scale * rows. */
+int demo_embed_tokens_bwd(const float* dpre, const int64_t* cam, float cam_scale, int32_t cam_all_tokens, void* dpatch,
+                          int32_t dt_patch, float* dcls, float* dpos, float* dcam, int32_t Bn, int32_t np, int32_t W, void* stream);
+/* dx = dy * act'(pre), fp32, n elements */
+int demo_act_bwd(const float* dy, const float* pre, int32_t kind, float* dx, int64_t n, void* stream);
+/* BatchNorm1d backward with batch statistics (same grouping / gate conventions as demo_batchnorm_fwd);
+ * dw, db are accumulated into; dgate (Bn,n_inner,n_outer) is accumulated into with atomics (zero it first). */
+int demo_batchnorm_bwd(const float* dy, const float* x, const float* w, const float* b, const float* save_mean,
+                       const float* save_invstd, float* dx, int32_t accumulate_dx, float* dw, float* db, int32_t Bn, int32_t F,
+                       int32_t gsz, int32_t n_inner, int32_t n_outer, int64_t pstride, const float* gate, float* dgate, void* stream);
+/* Fused flat Adam step over the flat fp32 parameter buffer (solver/make_optimizer.py: torch.optim.Adam with L2 weight
+ * decay; all parameter groups of the reference share lr and decay): updates p, m, v, optionally writes the bf16 weight
+ * shadow and zeroes g.  step >= 1 is the 1-based update count used for bias correction. */
+int demo_adam_step(float* p, float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int32_t step, int32_t zero_grad, void* stream);
+/* out[b, 0:C] += dtokens[b, 0, :]   (row-0 gradient of a token stream -> gradient of the global feature) */
+int demo_token0_grad(const float* dtokens, float* out, int64_t out_ld, int32_t Bn, int32_t L, int32_t C, void* stream);
+/* final trunk-output gradient (dtype dt): row 0 = dcls[b] (+ dtok row 0 if keep_row0); row l>=1 = dtok[b,l] + dmean[b]/(L-1);
+ * dtok / dcls / dmean may each be NULL (treated as zero). */
+int demo_tokens_grad(const float* dtok, const float* dcls, int64_t cls_ld, const float* dmean, int64_t mean_ld, int32_t keep_row0,
+                     void* out, int32_t dt, int32_t Bn, int32_t L, int32_t C, void* stream);
 
 #ifdef __cplusplus
 }

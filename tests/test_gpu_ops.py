@@ -284,9 +284,17 @@ def test_hdm_dropout_is_a_scaled_mask():
     Bs, L, Cd, Hh, ldS = 4, 129, 128, 2, 128
     S, tok = rnd(3 * Bs * L, ldS), rnd(3 * Bs * L, Cd, seed=1)
     _, _, p0 = ops.hdm_softmax_pool(S.to(DEV), tok.to(DEV), Bs, L, Cd, Hh, ldS, save_probs=True)
-    pooled, psum, p1 = ops.hdm_softmax_pool(S.to(DEV), tok.to(DEV), Bs, L, Cd, Hh, ldS, p_drop=0.1, seed=1234, save_probs=True)
-    _, _, p2 = ops.hdm_softmax_pool(S.to(DEV), tok.to(DEV), Bs, L, Cd, Hh, ldS, p_drop=0.1, seed=1234, save_probs=True)
+    pooled, psum, ppre, p1 = ops.hdm_softmax_pool(S.to(DEV), tok.to(DEV), Bs, L, Cd, Hh, ldS, p_drop=0.1, seed=1234, save_probs=True,
+                                                  save_probs_post=True)
+    _, _, _, p2 = ops.hdm_softmax_pool(S.to(DEV), tok.to(DEV), Bs, L, Cd, Hh, ldS, p_drop=0.1, seed=1234, save_probs=True,
+                                       save_probs_post=True)
     assert torch.equal(p1, p2)                                               # counter-based: reproducible for backward
+    assert torch.equal(ppre, p0)                                             # the saved softmax is the pre-dropout one
+    tf = tok.reshape(3, Bs, L, Cd)
+    for br, st in enumerate(STREAMS):                                        # pooled uses the post-dropout probabilities
+        x = torch.cat([tf[m] for m in st], 1)
+        want = torch.einsum("bhl,blc->bhc", p1[:, br, :, :len(st) * L].cpu(), x)
+        torch.testing.assert_close(pooled[:, br].cpu(), want, rtol=1e-4, atol=1e-4)
     kept = p1 != 0
     valid = p0 > 0
     frac = 1 - kept[valid].float().mean().item()

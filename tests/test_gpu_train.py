@@ -1,0 +1,132 @@
+"""GPU: training-mode forward + hand-written backward schedule against torch autograd of the CPU oracle.
+
+HDM dropout is switched off for exact comparison (its mask comes from the kernel's own counter RNG; the dropout
+kernels are checked in test_gpu_ops*.py with the mask fed back to the reference formula)."""
+import pytest
+import torch
+
+from demo2_amd.modeling import make_model
+from demo2_amd.modeling.hip_backward import TrainStep, make_loss_fn, total_loss
+from oracle import demo_oracle as O
+from util import make_cfg, small_cfg, spec_of, synth_batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def build(cfg, classes, cams, dtype, seed=0):
+    torch.manual_seed(seed)
+    m = make_model(cfg, classes, cams, 0)
+    sd = O.init_state_dict(spec_of(m), seed=seed + 1)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train().set_compute_dtype(dtype)
+    m.geom.hdm_dropout = 0.0
+    return m, sd
+
+
+def oracle_step(sd, spec, x, cam, target, idw, trw):
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    upd = {}
+    out = O.model_forward(sdg, spec, x, cam, training=True, updates=upd)
+    loss = O.train_loss(out, target, idw, trw)
+    loss.backward()
+    return out, loss, {k: v.grad for k, v in sdg.items() if v.requires_grad and v.grad is not None}, upd
+
+
+def rel_err(a, b):
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+@pytest.mark.parametrize("arch,direct,head", [("clip", 1, 4), ("vit", 1, 2), ("clip", 0, 4)])
+def test_small_train_step_fp32(arch, direct, head):
+    cfg = small_cfg(arch, head=head, direct=direct)
+    m, sd = build(cfg, 11, 3, torch.float32)
+    spec = spec_of(m)
+    spec.hdm_dropout = 0.0
+    x, cam = synth_batch(8, 64, 32, 3)
+    target = torch.tensor([0, 0, 1, 1, 2, 2, 3, 3])
+    idw, trw = float(cfg.MODEL.ID_LOSS_WEIGHT), float(cfg.MODEL.TRIPLET_LOSS_WEIGHT)
+    out_ref, loss_ref, grads_ref, upd = oracle_step(sd, spec, x, cam, target, idw, trw)
+
+    out = m({k: v.to(DEV) for k, v in x.items()}, label=target.to(DEV), cam_label=cam.to(DEV))
+    assert len(out) == len(out_ref) and out[-1] == 0
+    for a, b in zip(out[:-1], out_ref[:-1]):
+        torch.testing.assert_close(a.detach().cpu(), b.detach(), rtol=2e-4, atol=2e-4)
+    loss = total_loss(out, target.to(DEV), make_loss_fn(cfg))
+    torch.testing.assert_close(loss.detach().cpu(), loss_ref.detach(), rtol=1e-4, atol=1e-4)
+    loss.backward()
+    torch.cuda.synchronize()
+    got = {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.requires_grad}
+    frozen = {n for n, p in m.named_parameters() if not p.requires_grad}
+    assert frozen == {n for n in grads_ref if n.startswith("bottleneck") and n.endswith(".bias")}      # make_model.py:137,177
+    grads_ref = {n: v for n, v in grads_ref.items() if n not in frozen}
+    assert set(grads_ref) <= set(got)
+    bad = []
+    for n, gr in grads_ref.items():
+        e = rel_err(got[n], gr)
+        if e > 2e-3 and (got[n] - gr).abs().max() > 1e-6:
+            bad.append((n, e))
+    assert not bad, bad[:10]
+    # parameters the oracle gives no gradient to (key bias of HDM: cancels in the softmax) must be exactly zero here too
+    for n in got:
+        if n not in grads_ref:
+            assert got[n].abs().max() == 0, n
+    # BatchNorm running statistics and counters
+    msd = m.state_dict()
+    for k, v in upd.items():
+        torch.testing.assert_close(msd[k].cpu().to(v.dtype), v, rtol=1e-4, atol=1e-5)
+
+
+def test_small_train_step_bf16_and_adam():
+    cfg = small_cfg("clip")
+    m, sd = build(cfg, 11, 3, torch.bfloat16)
+    spec = spec_of(m)
+    spec.hdm_dropout = 0.0
+    x, cam = synth_batch(8, 64, 32, 3)
+    target = torch.tensor([0, 0, 1, 1, 2, 2, 3, 3])
+    out_ref, loss_ref, grads_ref, _ = oracle_step(sd, spec, x, cam, target, 0.25, 1.0)
+    ts = TrainStep(m, cfg, 1, lr=1e-3, optimizer=False)
+    loss = ts.step({k: v.to(DEV) for k, v in x.items()}, target.to(DEV), cam.to(DEV))
+    assert abs(loss.item() - loss_ref.item()) < 0.05 * abs(loss_ref.item()) + 0.02
+    got = {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.requires_grad}
+    big = [n for n, gr in grads_ref.items() if gr.norm() > 1e-3 and n in got]       # `got` has no entry for the frozen BNNeck biases
+    errs = {n: rel_err(got[n], grads_ref[n]) for n in big}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    assert sum(e < 0.15 for e in errs.values()) >= 0.95 * len(errs), worst      # bf16 activations/gradients through 2 blocks
+    # fused flat Adam == torch.optim.Adam on the same (parameter, gradient) pairs
+    params = {n: p.detach().cpu().clone().requires_grad_(True) for n, p in m.named_parameters() if p.requires_grad}
+    for n, p in params.items():
+        p.grad = got[n].clone()
+    opt = torch.optim.Adam([{"params": [p], "lr": 1e-3, "weight_decay": 1e-4} for p in params.values()])
+    opt.step()
+    m.adam_step(ts.m, ts.v, 1e-3, 0.9, 0.999, 1e-8, 1e-4, 1)
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            torch.testing.assert_close(p.detach().cpu(), params[n].detach(), rtol=1e-5, atol=1e-6)
+            assert p.grad.abs().max() == 0                                   # cleared by the fused step
+    sh = m.ptab.shadow[m.ptab.off("classifier.weight"):m.ptab.off("classifier.weight") + 10].float().cpu()
+    torch.testing.assert_close(sh, m.classifier.weight.detach().cpu().reshape(-1)[:10].bfloat16().float(), rtol=0, atol=0)
+
+
+def test_full_size_train_step_fp32_grads():
+    """Config A at full size, B=4 (2 ids x 2): loss and a sample of gradients against the oracle."""
+    cfg = make_cfg("RGBNT201")
+    m, sd = build(cfg, 171, 4, torch.float32)
+    spec = spec_of(m)
+    spec.hdm_dropout = 0.0
+    x, cam = synth_batch(4, 256, 128, 4)
+    target = torch.tensor([5, 5, 9, 9])
+    out_ref, loss_ref, grads_ref, _ = oracle_step(sd, spec, x, cam, target, 0.25, 1.0)
+    out = m({k: v.to(DEV) for k, v in x.items()}, label=target.to(DEV), cam_label=cam.to(DEV))
+    loss = total_loss(out, target.to(DEV), make_loss_fn(cfg))
+    torch.testing.assert_close(loss.detach().cpu(), loss_ref.detach(), rtol=2e-4, atol=2e-4)
+    loss.backward()
+    names = ["BACKBONE.base.conv1.weight", "BACKBONE.base.positional_embedding", "BACKBONE.cv_embed",
+             "BACKBONE.base.transformer.resblocks.0.attn.in_proj_weight", "BACKBONE.base.transformer.resblocks.5.mlp.c_fc.weight",
+             "BACKBONE.base.transformer.resblocks.11.ln_2.weight", "BACKBONE.base.proj", "rgb_reduce.1.weight",
+             "generalFusion.rnt.in_proj_weight", "generalFusion.rn_token", "generalFusion.moe.experts.2.expertHead.3.mlp.0.weight",
+             "generalFusion.moe.gating_network.gate.k_.weight", "classifier_moe.weight", "bottleneck.weight"]
+    pd = dict(m.named_parameters())
+    for n in names:
+        e = rel_err(pd[n].grad.detach().cpu(), grads_ref[n])
+        assert e < 5e-3, (n, e)
