@@ -44,6 +44,7 @@ PROTOTYPES = {
     "demo_abi_version": [],
     "demo_gemm": [C.POINTER(GemmDesc), _P],
     "demo_gemm_desc_size": [],
+    "demo_gemm_force_tile": [C.c_int],
     "demo_gemm_path": [C.POINTER(GemmDesc)],
     "demo_cast_f32_bf16": [_P, _P, _L, _P],
     "demo_cast_bf16_f32": [_P, _P, _L, _P],
@@ -63,7 +64,7 @@ PROTOTYPES = {
     "demo_hdm_softmax_pool_bwd": [_P, _P, _P, _P, _I, _P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _U64, _P],
     "demo_hdm_vbias_bwd": [_P, _P, _L, _P, _P, _P, _I, _I, _I, _P],
     "demo_atmoe_gate_softmax_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "demo_gemm_tn_bf16": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _F, _I, _P],
+    "demo_gemm_tn_bf16": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _F, _I, _P, _P],
     "demo_attention_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "demo_embed_tokens_bwd": [_P, _P, _F, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P],
     "demo_act_bwd": [_P, _P, _I, _P, _L, _P],

@@ -24,17 +24,20 @@ __global__ __launch_bounds__(256) void embed_tokens_bwd_kernel(const float* __re
                                                                float cam_scale, int cam_all, TP* __restrict__ dpatch,
                                                                float* __restrict__ dcls, float* __restrict__ dpos,
                                                                float* __restrict__ dcam, int Bn, int np, int W) {
+  // grid (token position, batch slab): partial sums over the slab's images, combined with fp32 atomics
   const int t = blockIdx.x, L = np + 1;
+  const int per = (Bn + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(Bn, b0 + per);
   for (int c = threadIdx.x; c < W; c += blockDim.x) {
     float s = 0.f;
-    for (int b = 0; b < Bn; ++b) {
+    for (int b = b0; b < b1; ++b) {
       const float v = dpre[((int64_t)b * L + t) * W + c];
       s += v;
       if (t > 0) io<TP>::st(dpatch + ((int64_t)b * np + (t - 1)) * W + c, v);
       if (dcam && cam && (cam_all || t == 0)) atomicAdd(&dcam[cam[b] * (int64_t)W + c], cam_scale * v);
     }
-    if (dpos) dpos[(int64_t)t * W + c] += s;
-    if (t == 0 && dcls) dcls[c] += s;
+    if (dpos) atomicAdd(&dpos[(int64_t)t * W + c], s);
+    if (t == 0 && dcls) atomicAdd(&dcls[c], s);
   }
 }
 
@@ -204,21 +207,31 @@ __global__ __launch_bounds__(256) void hdm_softmax_pool_bwd_kernel(const float* 
 }
 
 // do (Bs,7,C): dbias[br*stride + c] += sum_b do*psum ; dpsum[b,br,h] = sum_{c in head h} do * bias
+// blocks [0, 7): dbias of branch br (thread per channel, loop over samples, coalesced);
+// blocks [7, ...): dpsum, one wave per (sample, branch, head): dot over the head's channels
 __global__ __launch_bounds__(256) void hdm_vbias_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ bias, int64_t bias_stride,
                                                             const float* __restrict__ psum, float* __restrict__ dbias,
                                                             float* __restrict__ dpsum, int Bs, int C, int Hh) {
-  const int br = blockIdx.x;
   const int dh = C / Hh;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const float bv = bias[br * bias_stride + c];
-    float s = 0.f;
-    for (int b = 0; b < Bs; ++b) {
-      const float d = dy[((int64_t)b * 7 + br) * C + c];
-      s = fmaf(d, psum[((int64_t)b * 7 + br) * Hh + c / dh], s);
-      atomicAdd(&dpsum[((int64_t)b * 7 + br) * Hh + c / dh], d * bv);
+  if (blockIdx.x < 7) {
+    const int br = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float s = 0.f;
+      for (int b = 0; b < Bs; ++b) s = fmaf(dy[((int64_t)b * 7 + br) * C + c], psum[((int64_t)b * 7 + br) * Hh + c / dh], s);
+      dbias[br * bias_stride + c] += s;
     }
-    dbias[br * bias_stride + c] += s;
+    return;
   }
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)(blockIdx.x - 7) * 4 + (threadIdx.x >> 6);       // (b*7 + br)*Hh + h
+  if (item >= (int64_t)Bs * 7 * Hh) return;
+  const int h = (int)(item % Hh);
+  const int64_t bb = item / Hh;
+  const int br = (int)(bb % 7);
+  float a = 0.f;
+  for (int e = lane; e < dh; e += 64) a = fmaf(dy[bb * C + h * dh + e], bias[br * bias_stride + h * dh + e], a);
+  a = wave_sum(a);
+  if (lane == 0) dpsum[item] += a;
 }
 
 // out[b, c] += src[(b*L + 0), c]   (row-0 gradient of a token stream -> the (B, ld) global-feature gradient)
@@ -301,11 +314,12 @@ extern "C" int demo_embed_tokens_bwd(const float* dpre, const int64_t* cam, floa
                                      int32_t dt_patch, float* dcls, float* dpos, float* dcam, int32_t Bn, int32_t np, int32_t W,
                                      void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  const dim3 egrid(np + 1, (unsigned)(Bn >= 64 ? 16 : (Bn >= 8 ? 4 : 1)));
   if (dt_patch == DEMO_BF16)
-    hipLaunchKernelGGL(embed_tokens_bwd_kernel<bf16_t>, dim3(np + 1), dim3(256), 0, s, dpre, cam, cam_scale, cam_all_tokens,
+    hipLaunchKernelGGL(embed_tokens_bwd_kernel<bf16_t>, egrid, dim3(256), 0, s, dpre, cam, cam_scale, cam_all_tokens,
                        (bf16_t*)dpatch, dcls, dpos, dcam, Bn, np, W);
   else
-    hipLaunchKernelGGL(embed_tokens_bwd_kernel<float>, dim3(np + 1), dim3(256), 0, s, dpre, cam, cam_scale, cam_all_tokens,
+    hipLaunchKernelGGL(embed_tokens_bwd_kernel<float>, egrid, dim3(256), 0, s, dpre, cam, cam_scale, cam_all_tokens,
                        (float*)dpatch, dcls, dpos, dcam, Bn, np, W);
   DEMO_LAUNCH_CHECK("demo_embed_tokens_bwd");
   return 0;
@@ -362,7 +376,8 @@ extern "C" int demo_hdm_softmax_pool_bwd(const float* dpooled, const float* dpsu
 
 extern "C" int demo_hdm_vbias_bwd(const float* dy, const float* bias, int64_t bias_stride, const float* psum, float* dbias, float* dpsum,
                                   int32_t Bs, int32_t C, int32_t Hh, void* stream) {
-  hipLaunchKernelGGL(hdm_vbias_bwd_kernel, dim3(7), dim3(256), 0, (hipStream_t)stream, dy, bias, bias_stride, psum, dbias, dpsum, Bs, C, Hh);
+  const unsigned nblk = 7 + (unsigned)cdiv64((int64_t)Bs * 7 * Hh, 4);
+  hipLaunchKernelGGL(hdm_vbias_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, bias, bias_stride, psum, dbias, dpsum, Bs, C, Hh);
   DEMO_LAUNCH_CHECK("demo_hdm_vbias_bwd");
   return 0;
 }

@@ -1,27 +1,25 @@
 // bf16 x bf16 -> fp32-accumulate MFMA GEMM for gfx950:  C[M,N] = epi(A[M,K] . B[N,K]^T)
-// Both operands K-contiguous (the forward layout of every nn.Linear on the path:
-// activations (rows, K) times weight (N, K)).
+// Both operands K-contiguous (the forward layout of every nn.Linear on the path: activations (rows, K) times
+// weight (N, K); the backward dX = dY W uses a transposed bf16 weight copy so it takes the same kernel).
 //
-// Structure (cdna_hip_programming.md section 5, "minimum 2-phase" form):
-//   * 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave =
-//     4x4 v_mfma_f32_16x16x32_bf16 tiles), BK = 64;
-//   * tiles staged HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), two LDS
-//     buffers, the next tile in flight while the current one is multiplied;
-//   * LDS image is lane-linear per wave instruction, so the bank-conflict XOR swizzle
-//     (16-B chunk ^= (row>>1)&7) is applied on the per-lane SOURCE address and again on the
-//     ds_read_b128 fragment address (rule 21 of the guide);
-//   * MFMA operands are passed swapped (B fragment as the A operand) so that every lane ends
-//     up with 4 consecutive output columns -> 16-B / 8-B epilogue accesses for bias,
-//     residual and the store;
-//   * workgroup -> tile map is XCD-aware: consecutive ids of one XCD walk a group of 8
-//     row-panels against one weight panel so both stay in that XCD's L2.
+// Structure (cdna_hip_programming.md section 5):
+//   * BM x BN output tile per workgroup, BK = 64; two configurations:
+//       256 x 256, 8 waves as 2(M) x 4(N), 128 x 64 per wave (8 x 4 MFMA tiles)  -- the large products; halves the
+//                 L2 -> LDS bytes per FLOP of the 128^2 tile (at full MFMA rate a 128^2 tile needs the whole L2 bandwidth);
+//       128 x 128, 4 waves as 2 x 2, 64 x 64 per wave                              -- N not a multiple of 256 / small M;
+//   * tiles staged HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip), two LDS buffers, the next
+//     K-tile in flight while the current one is multiplied;
+//   * LDS image is lane-linear per wave instruction, so the bank-conflict XOR swizzle (16-B chunk ^= (row>>1)&7)
+//     is applied on the per-lane SOURCE address and again on the ds_read_b128 fragment address (rule 21);
+//   * MFMA operands are passed swapped (B fragment as the A operand) so that every lane ends up with 4 consecutive
+//     output columns -> 16-B / 8-B epilogue accesses for bias, residual, act'(pre) and the store;
+//   * workgroup -> tile map is XCD-aware: consecutive ids of one XCD walk a group of row-panels against one weight
+//     panel so both stay in that XCD's L2.
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;      // 16 KiB per operand tile
-constexpr int BUF_BYTES = 2 * TILE_BYTES;    // A + B
+constexpr int BK = 64;
 constexpr int GROUP_M = 8;
 
 struct FArgs {
@@ -43,11 +41,14 @@ struct FArgs {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
+// stage ROWS x 64 bf16 (ROWS*128 B) with NW waves: 1 KiB (8 rows) per wave instruction
+template <int ROWS, int NW>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int64_t ld, int row0, int row_max, int k0,
                                            char* lds_tile, int wave, int lane) {
+  constexpr int NSEG = ROWS / 8;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int seg = j * 4 + wave;            // 1-KiB segment = 8 tile rows
+  for (int j = 0; j < NSEG / NW; ++j) {
+    const int seg = j * NW + wave;
     const int r = seg * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     int gr = row0 + r;
@@ -57,12 +58,104 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int64_t
   }
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const FArgs p) {
-  __shared__ __attribute__((aligned(1024))) char smem[2 * BUF_BYTES];
+// register staging (T14): global -> VGPR now, VGPR -> swizzled LDS later
+template <int ROWS, int NW>
+__device__ __forceinline__ void load_tile_regs(uint4 (&r)[ROWS / 8 / NW], const bf16_t* __restrict__ G, int64_t ld, int row0,
+                                               int row_max, int k0, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < ROWS / 8 / NW; ++j) {
+    int gr = row0 + (j * NW + wave) * 8 + (lane >> 3);
+    gr = gr < row_max ? gr : row_max - 1;
+    r[j] = *reinterpret_cast<const uint4*>(G + (int64_t)gr * ld + k0 + (lane & 7) * 8);
+  }
+}
+template <int ROWS, int NW>
+__device__ __forceinline__ void write_tile_regs(const uint4 (&r)[ROWS / 8 / NW], char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < ROWS / 8 / NW; ++j) {
+    const int row = (j * NW + wave) * 8 + (lane >> 3);
+    *reinterpret_cast<uint4*>(lds_tile + row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4)) = r[j];
+  }
+}
+
+// bias -> (save pre-activation) -> activation -> * act'(pre) -> + residual -> (+= C) -> store, for 4 consecutive columns
+__device__ __forceinline__ void epi4(const FArgs& p, const float* __restrict__ bias, int64_t coff, int m, int n, float (&v)[4]) {
+  if (bias) {
+    const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
+    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+  }
+  const int64_t ci = coff + (int64_t)m * p.ldc + n;
+  if (p.pre_out) {
+    if (p.dtC == DEMO_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.pre_out) + ci) = make_float4(v[0], v[1], v[2], v[3]);
+    else io<bf16_t>::st4(reinterpret_cast<bf16_t*>(p.pre_out) + ci, make_float4(v[0], v[1], v[2], v[3]));
+  }
+  if (p.act != DEMO_ACT_NONE) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act);
+  }
+  if (p.pre) {
+    float4 pr;
+    if (p.dtPre == DEMO_BF16) pr = io<bf16_t>::ld4(reinterpret_cast<const bf16_t*>(p.pre) + ci);
+    else pr = io<float>::ld4(reinterpret_cast<const float*>(p.pre) + ci);
+    v[0] *= act_grad(pr.x, p.act_grad_kind); v[1] *= act_grad(pr.y, p.act_grad_kind);
+    v[2] *= act_grad(pr.z, p.act_grad_kind); v[3] *= act_grad(pr.w, p.act_grad_kind);
+  }
+  if (p.residual) {
+    const float4 r4 = *reinterpret_cast<const float4*>(p.residual + ci);
+    v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+  }
+  if (p.dtC == DEMO_F32) {
+    float* c = reinterpret_cast<float*>(p.C) + ci;
+    if (p.accumulate) {
+      const float4 o = *reinterpret_cast<const float4*>(c);
+      v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+    }
+    *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    io<bf16_t>::st4(reinterpret_cast<bf16_t*>(p.C) + ci, make_float4(v[0], v[1], v[2], v[3]));
+  }
+}
+
+__device__ __forceinline__ unsigned lds_off(const char* p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+// four ds_read_b128 of tile rows 0 / 16 / 32 / 48 (2048-B apart) from one base; NOT waited for here
+__device__ __forceinline__ void lds_read4(bf16x8 (&f)[4], unsigned base) {
+  asm volatile("ds_read_b128 %0, %4\n\t"
+               "ds_read_b128 %1, %4 offset:2048\n\t"
+               "ds_read_b128 %2, %4 offset:4096\n\t"
+               "ds_read_b128 %3, %4 offset:6144"
+               : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3])
+               : "v"(base)
+               : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else static_assert(N == 0, "add the literal");
+}
+
+// NSTAGE LDS buffers; tiles t+1 .. t+NSTAGE-1 are in flight (LDS-DMA) while tile t is multiplied.  One raw s_barrier per
+// K-step; the wait before it is a COUNTED vmcnt that leaves the younger tiles' loads outstanding (a __syncthreads()
+// would drain them: cdna_hip_programming.md "Pipelining across barriers").
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool RS = false>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN * 64 * ((BM + BN) * BK * 2 * NSTAGE > 80 * 1024 ? 1 : 2)) / 256)
+void gemm_bf16_nt_kernel(const FArgs p) {
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;       // MFMA tiles per wave
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, BUF_BYTES = A_BYTES + B_BYTES;
+  constexpr int LPT = (BM + BN) / 8 / NW;                   // LDS-DMA instructions per wave per K-tile
+  __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * BUF_BYTES];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
 
   // ---- XCD-aware tile id ------------------------------------------------------------------
   const int nwg = p.ntm * p.ntn;
@@ -80,11 +173,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const FArgs p) {
   const bf16_t* A = p.A + z * p.sA;
   const bf16_t* B = p.B + z * p.sB;
 
-  f32x4 acc[4][4];
+  f32x4 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // per-lane fragment byte offsets inside a tile (row part + swizzled chunk for k-step 0 / 1)
   const int frow = lane & 15;
@@ -93,83 +186,152 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const FArgs p) {
   const int foff1 = frow * 128 + ((4 + (lane >> 4)) ^ sw) * 16;
 
   const int nk = p.K / BK;
-  stage_tile(A, p.lda, m0, p.M, 0, smem, wave, lane);
-  stage_tile(B, p.ldb, n0, p.N, 0, smem + TILE_BYTES, wave, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  for (int t = 0; t < nk; ++t) {
-    char* cur = smem + (t & 1) * BUF_BYTES;
-    if (t + 1 < nk) {
-      char* nxt = smem + ((t + 1) & 1) * BUF_BYTES;
-      stage_tile(A, p.lda, m0, p.M, (t + 1) * BK, nxt, wave, lane);
-      stage_tile(B, p.ldb, n0, p.N, (t + 1) * BK, nxt + TILE_BYTES, wave, lane);
+  uint4 ra[RS ? BM / 8 / NW : 1], rb[RS ? BN / 8 / NW : 1];      // register staging (RS): one K-tile in VGPRs
+  if constexpr (RS) {
+    static_assert(NSTAGE == 2, "register staging uses two LDS buffers");
+    load_tile_regs<BM, NW>(ra, A, p.lda, m0, p.M, 0, wave, lane);
+    load_tile_regs<BN, NW>(rb, B, p.ldb, n0, p.N, 0, wave, lane);
+    write_tile_regs<BM, NW>(ra, smem, wave, lane);
+    write_tile_regs<BN, NW>(rb, smem + A_BYTES, wave, lane);
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) {
+      if (s < nk) {
+        stage_tile<BM, NW>(A, p.lda, m0, p.M, s * BK, smem + s * BUF_BYTES, wave, lane);
+        stage_tile<BN, NW>(B, p.ldb, n0, p.N, s * BK, smem + s * BUF_BYTES + A_BYTES, wave, lane);
+      }
     }
-    const char* la = cur + wr * (64 * 128);
-    const char* lb = cur + TILE_BYTES + wc * (64 * 128);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int fo = kk ? foff1 : foff0;
-      bf16x8 af[4], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(la + i * 2048 + fo);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(lb + j * 2048 + fo);
+  }
+
+  int slot = 0;                                   // LDS buffer of tile t
+  for (int t = 0; t < nk; ++t) {
+    if constexpr (RS) {
+      // T14 async-stage split: issue tile t+1's global loads now (they fly under this tile's MFMAs) and write them
+      // to the other LDS buffer after the multiply; one barrier per K-step.
+      if (t + 1 < nk) {
+        load_tile_regs<BM, NW>(ra, A, p.lda, m0, p.M, (t + 1) * BK, wave, lane);
+        load_tile_regs<BN, NW>(rb, B, p.ldb, n0, p.N, (t + 1) * BK, wave, lane);
+      }
+    } else {
+      // tile t has landed once at most `younger` tiles' loads of this wave are still outstanding
+      const int younger = min(NSTAGE - 2, nk - 1 - t);
+      if (NSTAGE >= 4 && younger >= 2) wait_vmcnt<2 * LPT>();
+      else if (NSTAGE >= 3 && younger >= 1) wait_vmcnt<LPT>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();               // every wave's part of tile t landed; every wave is done with tile t-1
+      if (t + NSTAGE - 1 < nk) {
+        const int ns = slot == 0 ? NSTAGE - 1 : slot - 1;        // buffer of tile t-1 == buffer of tile t+NSTAGE-1
+        char* nxt = smem + ns * BUF_BYTES;
+        stage_tile<BM, NW>(A, p.lda, m0, p.M, (t + NSTAGE - 1) * BK, nxt, wave, lane);
+        stage_tile<BN, NW>(B, p.ldb, n0, p.N, (t + NSTAGE - 1) * BK, nxt + A_BYTES, wave, lane);
+      }
+    }
+    char* cur = smem + slot * BUF_BYTES;
+    slot = slot + 1 == NSTAGE ? 0 : slot + 1;
+    const char* la = cur + wr * (TM * 16 * 128);
+    const char* lb = cur + A_BYTES + wc * (TN * 16 * 128);
+    if constexpr (TM * TN <= 16) {
+      // all 2*(TM+TN) fragment reads of the K-step are issued before the first MFMA: one exposed LDS latency per
+      // K-step instead of one per 8-MFMA group (the compiler then waits with counted lgkmcnt as data arrives)
+      // The reads are inline asm so that the waits can be COUNTED by hand (hipcc waits lgkmcnt(0) for its own loads
+      // here): k-half 0 is multiplied while k-half 1 is still arriving.  Order is pinned by sched_barrier(0) after
+      // each wait (cdna_hip_programming.md 5.7 form (iii), rule 18).
+      static_assert(TM == 4 && TN == 4, "hand-scheduled K-step is written for 4x4 MFMA tiles per wave");
+      bf16x8 af[2][4], bfr[2][4];
+      const unsigned ab0 = lds_off(la + foff0), ab1 = lds_off(la + foff1);
+      const unsigned bb0 = lds_off(lb + foff0), bb1 = lds_off(lb + foff1);
+      lds_read4(bfr[0], bb0);
+      lds_read4(af[0], ab0);
+      lds_read4(bfr[1], bb1);
+      lds_read4(af[1], ab1);
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[0][j], af[0][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);          // keep k-half 0's MFMAs above the wait for k-half 1
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[1][j], af[1][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int fo = kk ? foff1 : foff0;
+        bf16x8 af[TM], bfr[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(lb + j * 2048 + fo);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(la + i * 2048 + fo);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (RS) {
+      if (t + 1 < nk) {
+        char* nxt = smem + slot * BUF_BYTES;      // `slot` already points at tile t+1's buffer
+        write_tile_regs<BM, NW>(ra, nxt, wave, lane);
+        write_tile_regs<BN, NW>(rb, nxt + A_BYTES, wave, lane);
+      }
+      __syncthreads();
+    }
   }
 
-  // ---- epilogue: lane holds C[m][n .. n+3] -------------------------------------------------
+  // ---- epilogue ---------------------------------------------------------------------------------
   const int64_t coff = z * p.sC;
   const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
-  const int ng = (lane >> 4) * 4;
+  if constexpr (BM * BN * 4 <= NSTAGE * BUF_BYTES) {
+    // Stage the fp32 tile through LDS (the K-loop buffers are free now) and write whole rows: every wave instruction
+    // then covers 1-2 full tile rows with 16-B accesses per lane for bias / act'(pre) / residual / C.  The direct form
+    // (16 narrow 8-B stores per lane to 16 different rows) is store-ISSUE bound: ~4 us per 128^2 tile (guide, T21).
+    __syncthreads();                                      // all waves are done reading the last K-tile
+    float* ct = reinterpret_cast<float*>(smem);
+    const int g4 = lane >> 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wr * 64 + i * 16 + frow;
-    if (m >= p.M) continue;
+    for (int i = 0; i < TM; ++i) {
+      const int r = wr * (TM * 16) + i * 16 + frow;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wc * 64 + j * 16 + ng;
-      float v[4] = {acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha};
-      if (bias) {
-        const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
-        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+      for (int j = 0; j < TN; ++j) {
+        const int slot = (wc * TN * 4 + j * 4 + g4) ^ (frow & 7);
+        *reinterpret_cast<float4*>(ct + r * BN + slot * 4) =
+            make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha);
       }
-      const int64_t ci = coff + (int64_t)m * p.ldc + n;
-      if (p.pre_out) {
-        if (p.dtC == DEMO_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.pre_out) + ci) = make_float4(v[0], v[1], v[2], v[3]);
-        else io<bf16_t>::st4(reinterpret_cast<bf16_t*>(p.pre_out) + ci, make_float4(v[0], v[1], v[2], v[3]));
-      }
-      if (p.act != DEMO_ACT_NONE) {
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;                           // 8-float chunks per row
+#pragma unroll 4
+    for (int it = 0; it < (BM * CPR) / (NW * 64); ++it) {
+      const int idx = it * (NW * 64) + threadIdx.x;
+      const int r = idx / CPR, c = idx - r * CPR;
+      const int m = m0 + r;
+      if (m >= p.M) continue;
+      const float4 lo = *reinterpret_cast<const float4*>(ct + r * BN + (((2 * c) ^ (r & 7)) << 2));
+      const float4 hi = *reinterpret_cast<const float4*>(ct + r * BN + (((2 * c + 1) ^ (r & 7)) << 2));
+      float v0[4] = {lo.x, lo.y, lo.z, lo.w}, v1[4] = {hi.x, hi.y, hi.z, hi.w};
+      epi4(p, bias, coff, m, n0 + c * 8, v0);
+      epi4(p, bias, coff, m, n0 + c * 8 + 4, v1);
+    }
+  } else {
+    // direct form: lane holds C[m][n .. n+3] for each of its MFMA tiles
+    const int ng = (lane >> 4) * 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act);
-      }
-      if (p.pre) {
-        float4 pr;
-        if (p.dtPre == DEMO_BF16) pr = io<bf16_t>::ld4(reinterpret_cast<const bf16_t*>(p.pre) + ci);
-        else pr = io<float>::ld4(reinterpret_cast<const float*>(p.pre) + ci);
-        v[0] *= act_grad(pr.x, p.act_grad_kind); v[1] *= act_grad(pr.y, p.act_grad_kind);
-        v[2] *= act_grad(pr.z, p.act_grad_kind); v[3] *= act_grad(pr.w, p.act_grad_kind);
-      }
-      if (p.residual) {
-        const float4 r4 = *reinterpret_cast<const float4*>(p.residual + ci);
-        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-      }
-      if (p.dtC == DEMO_F32) {
-        float* c = reinterpret_cast<float*>(p.C) + ci;
-        if (p.accumulate) {
-          const float4 o = *reinterpret_cast<const float4*>(c);
-          v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-        }
-        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        io<bf16_t>::st4(reinterpret_cast<bf16_t*>(p.C) + ci, make_float4(v[0], v[1], v[2], v[3]));
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wr * (TM * 16) + i * 16 + frow;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float v[4] = {acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha};
+        epi4(p, bias, coff, m, n0 + wc * (TN * 16) + j * 16 + ng, v);
       }
     }
   }
@@ -183,7 +345,7 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 int demo_gemm_bf16_eligible(const demo_gemm_desc& d) {
   if (d.dtA != DEMO_BF16 || d.dtB != DEMO_BF16) return 0;
   if (d.a_cs != 1 || d.b_cs != 1) return 0;
-  if (d.K % BK || d.N % BN || d.M < 1) return 0;
+  if (d.K % BK || d.N % 128 || d.M < 1) return 0;
   if (d.a_rs % 8 || d.b_rs % 8 || d.c_rs % 4) return 0;
   if (!al16(d.A) || !al16(d.B) || !al16(d.C)) return 0;
   if (d.bias && !al16(d.bias)) return 0;
@@ -201,6 +363,9 @@ int demo_gemm_bf16_eligible(const demo_gemm_desc& d) {
   return 1;
 }
 
+static int g_force_tile = 0;   // test/bench hook: 128 or 256 forces a configuration, 0 = heuristic
+extern "C" int demo_gemm_force_tile(int t) { g_force_tile = t; return 0; }
+
 int demo_gemm_bf16(const demo_gemm_desc& d, hipStream_t s) {
   FArgs p;
   p.A = reinterpret_cast<const bf16_t*>(d.A);
@@ -216,10 +381,36 @@ int demo_gemm_bf16(const demo_gemm_desc& d, hipStream_t s) {
   p.sA = lvl1 ? d.sA1 : d.sA2; p.sB = lvl1 ? d.sB1 : d.sB2; p.sC = lvl1 ? d.sC1 : d.sC2; p.sBias = lvl1 ? d.sBias1 : d.sBias2;
   p.dtC = d.dtC; p.act = d.act; p.dtPre = d.dtPre; p.act_grad_kind = d.act_grad_kind; p.accumulate = d.accumulate;
   p.alpha = d.alpha;
-  p.ntm = (int)cdiv64(d.M, BM);
-  p.ntn = d.N / BN;
-  dim3 grid((unsigned)(p.ntm * p.ntn), (unsigned)(d.batch1 * d.batch2));
-  hipLaunchKernelGGL(gemm_bf16_nt_kernel, grid, dim3(256), 0, s, p);
+  const int nb = d.batch1 * d.batch2;
+  // configuration code = tile*10 + stages: 1282 (128^2, 2 buffers, 2 workgroups/CU), 1283, 1284 (1 workgroup/CU),
+  // 2562 (256^2, 8 waves), 2563 = 256x128 with 3 buffers
+  int cfg = g_force_tile ? g_force_tile : 1282;
+  if ((cfg == 2562) && d.N % 256) cfg = 1282;
+#define LAUNCH(BM_, BN_, WM_, WN_, NS_)                                                                                  \
+  do {                                                                                                                   \
+    p.ntm = (int)cdiv64(d.M, BM_);                                                                                       \
+    p.ntn = d.N / BN_;                                                                                                   \
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM_, BN_, WM_, WN_, NS_>), dim3((unsigned)(p.ntm * p.ntn), (unsigned)nb),    \
+                       dim3(WM_ * WN_ * 64), 0, s, p);                                                                   \
+  } while (0)
+#define LAUNCH_RS(BM_, BN_, WM_, WN_)                                                                                    \
+  do {                                                                                                                   \
+    p.ntm = (int)cdiv64(d.M, BM_);                                                                                       \
+    p.ntn = d.N / BN_;                                                                                                   \
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM_, BN_, WM_, WN_, 2, true>), dim3((unsigned)(p.ntm * p.ntn), (unsigned)nb), \
+                       dim3(WM_ * WN_ * 64), 0, s, p);                                                                   \
+  } while (0)
+  switch (cfg) {
+    case 2562: LAUNCH(256, 256, 2, 4, 2); break;
+    case 2563: LAUNCH(256, 128, 4, 2, 3); break;
+    case 1283: LAUNCH(128, 128, 2, 2, 3); break;
+    case 1284: LAUNCH(128, 128, 2, 2, 4); break;
+    case 1292: LAUNCH_RS(128, 128, 2, 2); break;
+    case 2592: LAUNCH_RS(256, 128, 4, 2); break;
+    default: LAUNCH(128, 128, 2, 2, 2); break;
+  }
+#undef LAUNCH
+#undef LAUNCH_RS
   DEMO_LAUNCH_CHECK("demo_gemm(bf16 mfma)");
   return 0;
 }

@@ -36,6 +36,7 @@ struct TArgs {
   int ntm, ntn;
   int use_atomics;      // 1: atomicAdd into C; 0: C = (accumulate ? C : 0) + result with plain stores
   int accumulate;
+  float* colsum;        // optional: colsum[m] += sum_r A[r, m]  (the bias gradient of the same Linear), atomics
 };
 
 // LDS-DMA staging of a full 64-row tile: rows [k0, k0+64) x cols [c0, c0+128)
@@ -80,6 +81,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const TArgs p) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // bias gradient for free: the waves that own the first column panel also multiply their A fragments by a fragment
+  // of ones, which leaves sum_r A[r, m] in every column of a 16x16 accumulator (4 extra MFMAs per 32-deep step)
+  const bool do_colsum = p.colsum != nullptr && tn == 0 && wc == 0;          // wave-uniform
+  f32x4 csum[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) csum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
   // transposed-read addressing: lane (g, idx=4q+pp): row 8g+q (+4), 8-B piece at column 4*pp of a 16-column block
   const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
@@ -130,11 +138,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const TArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      if (do_colsum) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) csum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, csum[i], 0, 0, 0);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
+  if (do_colsum && idx == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(p.colsum + m0 + wr * 64 + i * 16 + 4 * g + r, csum[i][r]);
+  }
   // D[row = m_local = 4g + reg][col = n_local = lane & 15]: per register 4 rows x 64 contiguous bytes
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -158,7 +176,7 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 }  // namespace
 
 extern "C" int demo_gemm_tn_bf16(const void* A, const void* B, float* C, int32_t Mo, int32_t No, int32_t Kr, int64_t lda, int64_t ldb,
-                                 int64_t ldc, float alpha, int32_t accumulate, void* stream) {
+                                 int64_t ldc, float alpha, int32_t accumulate, float* colsum, void* stream) {
   DEMO_REQUIRE(A && B && C, "demo_gemm_tn_bf16: null operand");
   DEMO_REQUIRE(Mo > 0 && No > 0 && Kr > 0 && Mo % BM == 0 && No % BN == 0, "demo_gemm_tn_bf16: Mo=%d No=%d must be multiples of 128", Mo, No);
   DEMO_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && al16(A) && al16(B), "demo_gemm_tn_bf16: operands must be 16-B aligned with ld %% 8 == 0");
@@ -178,6 +196,7 @@ extern "C" int demo_gemm_tn_bf16(const void* A, const void* B, float* C, int32_t
   p.splitk = (ktiles + kt_per - 1) / kt_per;
   p.use_atomics = p.splitk > 1;
   p.accumulate = accumulate;
+  p.colsum = colsum;
   if (p.use_atomics && !accumulate) {
     hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)No * sizeof(float), (size_t)Mo, s);
     if (e != hipSuccess) DEMO_FAIL(-2, "demo_gemm_tn_bf16: memset failed: %s", hipGetErrorString(e));

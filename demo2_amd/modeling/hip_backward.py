@@ -303,23 +303,19 @@ def trunk_backward(m, tape, dtokens):
         k, s = g.block_keys(i), tape.blocks[i]
         d_res = dxb if lp else dx                                   # gradient of the block output, GEMM operand dtype
         # x2 = x1 + fc2(u)
-        ops.gemm_tn(d_res, s["u"], G, out_off=P.off(k["fc2_w"]), ldc=4 * W, accumulate=True)
-        ops.colsum(d_res, out=G[P.off(k["fc2_b"]):P.off(k["fc2_b"]) + W], accumulate=True)
+        ops.gemm_tn(d_res, s["u"], G, out_off=P.off(k["fc2_w"]), ldc=4 * W, accumulate=True, colsum_out=G, colsum_off=P.off(k["fc2_b"]))
         dpre = ops.gemm(d_res, P.wt(k["fc2_w"], T), act_grad_pre=s["pre"], act_grad_kind=act)      # (M, 4W) = (dx W2) * act'(pre)
         # u = act(fc1(h2))
-        ops.gemm_tn(dpre, s["h2"], G, out_off=P.off(k["fc1_w"]), ldc=W, accumulate=True)
-        ops.colsum(dpre, out=G[P.off(k["fc1_b"]):P.off(k["fc1_b"]) + 4 * W], accumulate=True)
+        ops.gemm_tn(dpre, s["h2"], G, out_off=P.off(k["fc1_w"]), ldc=W, accumulate=True, colsum_out=G, colsum_off=P.off(k["fc1_b"]))
         dh2 = ops.gemm(dpre, P.wt(k["fc1_w"], T))                                                  # (M, W)
         ops.layernorm_bwd(dh2, s["x1"], P.f(k["ln2"] + ".weight"), s["mean2"], s["rstd2"], dx=dx, accumulate_dx=True,
                           dw=gw(k["ln2"] + ".weight"), db=gw(k["ln2"] + ".bias"), dx_lp=dxb)
         d_res = dxb if lp else dx
         # x1 = x + out_proj(a)
-        ops.gemm_tn(d_res, s["a"], G, out_off=P.off(k["proj_w"]), ldc=W, accumulate=True)
-        ops.colsum(d_res, out=G[P.off(k["proj_b"]):P.off(k["proj_b"]) + W], accumulate=True)
+        ops.gemm_tn(d_res, s["a"], G, out_off=P.off(k["proj_w"]), ldc=W, accumulate=True, colsum_out=G, colsum_off=P.off(k["proj_b"]))
         da = ops.gemm(d_res, P.wt(k["proj_w"], T))                                                 # (M, W)
         dqkv = ops.attention_bwd(s["qkv"], s["a"], da, s["lse"], Bn, L, g.heads)                   # (M, 3W)
-        ops.gemm_tn(dqkv, s["h1"], G, out_off=P.off(k["qkv_w"]), ldc=W, accumulate=True)
-        ops.colsum(dqkv, out=G[P.off(k["qkv_b"]):P.off(k["qkv_b"]) + 3 * W], accumulate=True)
+        ops.gemm_tn(dqkv, s["h1"], G, out_off=P.off(k["qkv_w"]), ldc=W, accumulate=True, colsum_out=G, colsum_off=P.off(k["qkv_b"]))
         dh1 = ops.gemm(dqkv, P.wt(k["qkv_w"], T))                                                  # (M, W)
         ops.layernorm_bwd(dh1, s["x"], P.f(k["ln1"] + ".weight"), s["mean1"], s["rstd1"], dx=dx, accumulate_dx=True,
                           dw=gw(k["ln1"] + ".weight"), db=gw(k["ln1"] + ".bias"), dx_lp=dxb)

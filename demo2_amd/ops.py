@@ -355,9 +355,11 @@ def atmoe_gate_softmax_bwd(dgates: Tensor, gates: Tensor, q: Tensor, k: Tensor, 
     return dq, dk
 
 
-def gemm_tn(a: Tensor, b: Tensor, out: Tensor, out_off: int = 0, ldc: Optional[int] = None, alpha: float = 1.0, accumulate: bool = True):
+def gemm_tn(a: Tensor, b: Tensor, out: Tensor, out_off: int = 0, ldc: Optional[int] = None, alpha: float = 1.0, accumulate: bool = True,
+            colsum_out: Optional[Tensor] = None, colsum_off: int = 0):
     """out_flat[out_off + m*ldc + n] (+)= alpha * sum_r a[r, m] * b[r, n]   (weight gradients: a = dY, b = X).
-    bf16 operands with 128-multiples take the MFMA kernel; everything else the generic strided kernel."""
+    bf16 operands with 128-multiples take the MFMA kernel; everything else the generic strided kernel.
+    colsum_out (optional): fp32 buffer that also receives += sum_r a[r, :] (the bias gradient), fused into the MFMA kernel."""
     _req_cuda(a, b, out)
     R, Mo = a.shape
     No = b.shape[1]
@@ -365,9 +367,12 @@ def gemm_tn(a: Tensor, b: Tensor, out: Tensor, out_off: int = 0, ldc: Optional[i
     ldc = No if ldc is None else ldc
     if (a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and Mo % 128 == 0 and No % 128 == 0 and a.stride(1) == 1
             and b.stride(1) == 1 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
+        cs = None if colsum_out is None else colsum_out.data_ptr() + 4 * colsum_off
         check(_lib.load().demo_gemm_tn_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr() + 4 * out_off, Mo, No, R, a.stride(0), b.stride(0), ldc,
-                                            float(alpha), int(accumulate), _stream()), "demo_gemm_tn_bf16")
+                                            float(alpha), int(accumulate), cs, _stream()), "demo_gemm_tn_bf16")
         return out
+    if colsum_out is not None:                      # bias gradient: colsum_out[colsum_off + m] += sum_r a[r, m]
+        colsum(a, out=colsum_out[colsum_off:colsum_off + Mo], accumulate=True)
     return gemm_raw(a, b, out, Mo, No, R, a.stride(1), a.stride(0), b.stride(1), b.stride(0), ldc, c_off=out_off, alpha=alpha,
                     accumulate=accumulate)
 

@@ -65,6 +65,7 @@ typedef struct demo_gemm_desc {
 } demo_gemm_desc;
 int demo_gemm(const demo_gemm_desc* d, void* stream);
 int demo_gemm_path(const demo_gemm_desc* d); /* 1 = bf16 MFMA kernel, 0 = generic kernel (what demo_gemm would pick) */
+int demo_gemm_force_tile(int tile); /* tuning hook: 128 / 256 forces that MFMA tile configuration, 0 = heuristic; returns 0 */
 int demo_gemm_desc_size(void); /* sizeof(demo_gemm_desc): lets a foreign binding verify its struct layout */
 
 /* ---- elementwise / layout ----------------------------------------------------------------- */
@@ -163,7 +164,9 @@ int demo_atmoe_gate_softmax_bwd(const float* dgates, const float* gates, const f
  * C[Mo,No] (+)= alpha * sum_r A[r,Mo] * B[r,No]; bf16 MFMA, split over the reduction with fp32 atomics.
  * dW of every nn.Linear in the trunk: A = dY (rows,N), B = X (rows,K) -> C = dW (N,K) inside the flat grad buffer. */
 int demo_gemm_tn_bf16(const void* A, const void* B, float* C, int32_t Mo, int32_t No, int32_t Kr, int64_t lda, int64_t ldb,
-                      int64_t ldc, float alpha, int32_t accumulate, void* stream);
+                      int64_t ldc, float alpha, int32_t accumulate, float* colsum, void* stream);
+/* colsum (optional, fp32 [Mo]): colsum[m] += sum_r A[r,m] -- the bias gradient of the same Linear, computed by the waves
+ * that already hold the A fragments (no extra pass over dY). */
 /* Self-attention backward (same packing as demo_attention_fwd; lse from the forward): dqkv (Bn*L, 3D). */
 int demo_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int32_t Bn,
                        int32_t L, int32_t H, int32_t dh, int32_t dt, void* stream);

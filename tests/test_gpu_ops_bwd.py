@@ -21,8 +21,11 @@ def test_gemm_tn_bf16_mfma(R, Mo, No):
     ops.gemm_tn(a.to(DEV), b.to(DEV), out, accumulate=True)
     torch.testing.assert_close(out.cpu(), base + want, rtol=2e-3, atol=2e-3 * R ** 0.5)
     out2 = torch.full((Mo, No), 7.0, device=DEV)
-    ops.gemm_tn(a.to(DEV), b.to(DEV), out2, accumulate=False, alpha=0.5)
+    cs = torch.ones(Mo + 8, device=DEV)                       # fused bias gradient: colsum of the A operand
+    ops.gemm_tn(a.to(DEV), b.to(DEV), out2, accumulate=False, alpha=0.5, colsum_out=cs, colsum_off=4)
     torch.testing.assert_close(out2.cpu(), 0.5 * want, rtol=2e-3, atol=2e-3 * R ** 0.5)
+    torch.testing.assert_close(cs.cpu()[4:4 + Mo], 1 + a.float().sum(0), rtol=1e-3, atol=1e-3 * R ** 0.5)
+    assert torch.equal(cs.cpu()[:4], torch.ones(4)) and torch.equal(cs.cpu()[4 + Mo:], torch.ones(4))
     # exact integer check of the transposing fragment reads (asymmetric operands)
     a2 = ((torch.arange(R)[:, None] * 3 + torch.arange(Mo)[None, :]) % 5).float()
     b2 = ((torch.arange(R)[:, None] + 2 * torch.arange(No)[None, :]) % 3).float()
