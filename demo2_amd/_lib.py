@@ -53,7 +53,8 @@ PROTOTYPES = {
     "demo_im2col": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "demo_embed_tokens": [_P, _I, _P, _P, _P, _P, _F, _I, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P],
     "demo_layernorm_fwd": [_P, _P, _P, _F, _P, _I, _P, _P, _I, _I, _P],
-    "demo_layernorm_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P],
+    "demo_layernorm_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P],
+    "demo_layernorm_bwd_workspace": [_I, _I],
     "demo_adam_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _P],
     "demo_batchnorm_fwd": [_P, _P, _P, _P, _P, _I, _F, _F, _P, _I, _P, _P, _I, _I, _I, _I, _I, _L, _L, _P, _P],
     "demo_attention_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -68,6 +69,7 @@ PROTOTYPES = {
     "demo_attention_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "demo_embed_tokens_bwd": [_P, _P, _F, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P],
     "demo_act_bwd": [_P, _P, _I, _P, _L, _P],
+    "demo_act_fwd": [_P, _I, _P, _L, _P],
     "demo_batchnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _L, _P, _P, _P],
     "demo_token0_grad": [_P, _P, _L, _I, _I, _I, _P],
     "demo_tokens_grad": [_P, _P, _L, _P, _L, _I, _P, _I, _I, _I, _I, _P],
@@ -98,6 +100,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing -> loud
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.demo_layernorm_bwd_workspace.restype = C.c_int64
     lib.demo_last_error.argtypes = []
     lib.demo_last_error.restype = C.c_char_p
     if lib.demo_gemm_desc_size() != C.sizeof(GemmDesc):

@@ -41,6 +41,11 @@ __global__ __launch_bounds__(256) void embed_tokens_bwd_kernel(const float* __re
   }
 }
 
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ pre, int kind, float* __restrict__ y, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = act_apply(pre[i], kind);
+}
+
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, int kind,
                                                       float* __restrict__ dx, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -322,6 +327,14 @@ extern "C" int demo_embed_tokens_bwd(const float* dpre, const int64_t* cam, floa
     hipLaunchKernelGGL(embed_tokens_bwd_kernel<float>, egrid, dim3(256), 0, s, dpre, cam, cam_scale, cam_all_tokens,
                        (float*)dpatch, dcls, dpos, dcam, Bn, np, W);
   DEMO_LAUNCH_CHECK("demo_embed_tokens_bwd");
+  return 0;
+}
+
+extern "C" int demo_act_fwd(const float* pre, int32_t kind, float* y, int64_t n, void* stream) {
+  int64_t g = cdiv64(n, 256);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, pre, kind, y, n);
+  DEMO_LAUNCH_CHECK("demo_act_fwd");
   return 0;
 }
 

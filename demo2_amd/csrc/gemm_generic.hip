@@ -15,6 +15,8 @@ template <typename T> __device__ __forceinline__ float ldg(const void* p, int64_
 
 struct GArgs {
   demo_gemm_desc d;
+  int splitk;   // > 1: blockIdx.z = batch * splitk + slice; slices combine with fp32 atomics (C pre-zeroed or accumulated into)
+  int kper;     // reduction elements per slice (multiple of GK)
 };
 
 template <typename TA, typename TB, typename TC>
@@ -23,7 +25,8 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GArgs args) {
   __shared__ float As[GK][GT + 4];
   __shared__ float Bs[GK][GT + 4];
 
-  const int z = blockIdx.z;
+  const int z = blockIdx.z / args.splitk, slice = blockIdx.z - z * args.splitk;
+  const int kbeg = slice * args.kper, kend = min(d.K, kbeg + args.kper);
   const int z1 = z / d.batch2, z2 = z % d.batch2;
   const TA* A = reinterpret_cast<const TA*>(d.A) + z1 * d.sA1 + z2 * d.sA2;
   const TB* B = reinterpret_cast<const TB*>(d.B) + z1 * d.sB1 + z2 * d.sB2;
@@ -46,17 +49,17 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GArgs args) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
 
-  for (int k0 = 0; k0 < d.K; k0 += GK) {
+  for (int k0 = kbeg; k0 < kend; k0 += GK) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = t + i * 256;
       int r, k;
       if (a_kfast) { r = idx >> 4; k = idx & 15; } else { r = idx & 63; k = idx >> 6; }
       const int gm = m0 + r, gk = k0 + k;
-      As[k][r] = (gm < d.M && gk < d.K) ? io<TA>::ld(A + (int64_t)gm * d.a_rs + (int64_t)gk * d.a_cs) : 0.f;
+      As[k][r] = (gm < d.M && gk < kend) ? io<TA>::ld(A + (int64_t)gm * d.a_rs + (int64_t)gk * d.a_cs) : 0.f;
       if (b_kfast) { r = idx >> 4; k = idx & 15; } else { r = idx & 63; k = idx >> 6; }
       const int gn = n0 + r, gk2 = k0 + k;
-      Bs[k][r] = (gn < d.N && gk2 < d.K) ? io<TB>::ld(B + (int64_t)gn * d.b_rs + (int64_t)gk2 * d.b_cs) : 0.f;
+      Bs[k][r] = (gn < d.N && gk2 < kend) ? io<TB>::ld(B + (int64_t)gn * d.b_rs + (int64_t)gk2 * d.b_cs) : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -82,8 +85,13 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GArgs args) {
       const int gn = n0 + tx * 4 + j;
       if (gn >= d.N) continue;
       float v = acc[i][j] * d.alpha;
-      if (bias) v += bias[gn];
       const int64_t ci = (int64_t)gm * d.c_rs + gn;
+      if (args.splitk > 1) {                       // fp32 C only, no non-linear epilogue (checked on the host)
+        if (bias && slice == 0) v += bias[gn];
+        atomicAdd(reinterpret_cast<float*>(d.C) + coff + ci, v);
+        continue;
+      }
+      if (bias) v += bias[gn];
       if (d.pre_out) io<TC>::st(reinterpret_cast<TC*>(d.pre_out) + coff + ci, v);
       v = act_apply(v, d.act);
       if (d.act_grad_pre) {
@@ -101,7 +109,32 @@ template <typename TA, typename TB>
 int launch_c(const demo_gemm_desc& d, hipStream_t s) {
   GArgs a;
   a.d = d;
-  dim3 grid((unsigned)cdiv64(d.N, GT), (unsigned)cdiv64(d.M, GT), (unsigned)(d.batch1 * d.batch2));
+  a.splitk = 1;
+  a.kper = d.K;
+  const int64_t tiles = cdiv64(d.N, GT) * cdiv64(d.M, GT) * d.batch1 * d.batch2;
+  // skinny products with a long reduction (classifier 128 x 171 x 3584, gate Linear 128 x 512 x 3584 ...): a handful of
+  // workgroups would walk K serially at one memory latency per 16-deep step -> split the reduction across workgroups
+  const bool linear_epi = d.act == DEMO_ACT_NONE && !d.pre_out && !d.act_grad_pre && !d.residual && d.dtC == DEMO_F32;
+  if (linear_epi && tiles < 128 && d.K >= 512) {
+    int sk = (int)(256 / tiles);
+    const int maxk = d.K / 128;
+    if (sk > maxk) sk = maxk;
+    if (sk > 64) sk = 64;
+    if (sk > 1) {
+      const int ksteps = (int)cdiv64(d.K, GK);
+      const int per = (int)cdiv64(ksteps, sk);
+      a.kper = per * GK;
+      a.splitk = (int)cdiv64(ksteps, per);
+      if (!d.accumulate) {                                       // slices add into C: clear it first (rows may be strided)
+        for (int z = 0; z < d.batch1 * d.batch2; ++z) {
+          float* c = reinterpret_cast<float*>(d.C) + (z / d.batch2) * d.sC1 + (z % d.batch2) * d.sC2;
+          hipError_t e = hipMemset2DAsync(c, (size_t)d.c_rs * sizeof(float), 0, (size_t)d.N * sizeof(float), (size_t)d.M, s);
+          if (e != hipSuccess) DEMO_FAIL(-2, "demo_gemm(generic): memset failed: %s", hipGetErrorString(e));
+        }
+      }
+    }
+  }
+  dim3 grid((unsigned)cdiv64(d.N, GT), (unsigned)cdiv64(d.M, GT), (unsigned)(d.batch1 * d.batch2 * a.splitk));
   if (d.dtC == DEMO_F32)
     hipLaunchKernelGGL((gemm_generic_kernel<TA, TB, float>), grid, dim3(256), 0, s, a);
   else

@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
                                                             const float* __restrict__ w, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dx,
                                                             int accumulate_dx, bf16_t* __restrict__ dx_lp, float* __restrict__ dw,
-                                                            float* __restrict__ db, int M, int D, int rows_per_block) {
+                                                            float* __restrict__ db, float* __restrict__ part, int M, int D,
+                                                            int rows_per_block) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [2][D]
   float* s_dw = sm;
   float* s_db = sm + D;
@@ -132,10 +133,35 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
     }
   }
   __syncthreads();
+  if (part) {            // two-stage: per-workgroup partials, summed by ln_bwd_reduce_kernel (no contended global atomics)
+    float* pr = part + (int64_t)blockIdx.x * 2 * D;
+    for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) pr[i] = sm[i];
+    return;
+  }
   for (int i = threadIdx.x; i < D; i += blockDim.x) {
     if (dw) atomicAdd(&dw[i], s_dw[i]);
     if (db) atomicAdd(&db[i], s_db[i]);
   }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int D, float* __restrict__ dw,
+                                                            float* __restrict__ db) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;      // column of the [2][D] partial rows
+  if (c >= 2 * D) return;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;       // grid.y slices of the partial rows, combined with a few atomics
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = b0;
+  for (; b + 4 <= b1; b += 4) {
+    s0 += part[(int64_t)b * 2 * D + c];
+    s1 += part[(int64_t)(b + 1) * 2 * D + c];
+    s2 += part[(int64_t)(b + 2) * 2 * D + c];
+    s3 += part[(int64_t)(b + 3) * 2 * D + c];
+  }
+  for (; b < b1; ++b) s0 += part[(int64_t)b * 2 * D + c];
+  const float s = (s0 + s1) + (s2 + s3);
+  if (c < D) { if (dw) atomicAdd(&dw[c], s); }
+  else if (db) atomicAdd(&db[c - D], s);
 }
 
 // BatchNorm1d: one thread per feature, coalesced across features; Bn <= a few thousand rows.
@@ -204,21 +230,32 @@ extern "C" int demo_layernorm_fwd(const float* x, const float* w, const float* b
 
 extern "C" int demo_layernorm_bwd(const void* dy, int32_t dtDy, const float* x, const float* w, const float* mean,
                                   const float* rstd, float* dx, int32_t accumulate_dx, void* dx_bf16, float* dw, float* db,
-                                  int32_t M, int32_t D, void* stream) {
+                                  float* workspace, int64_t workspace_elems, int32_t M, int32_t D, void* stream) {
   DEMO_REQUIRE(D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "demo_layernorm_bwd: D=%d unsupported", D);
   hipStream_t s = (hipStream_t)stream;
   const int rows_per_block = 16;      // 4 rows per wave: ~3000 workgroups at 3B*L = 49536 rows keep every CU's memory pipes full
-  dim3 grid((unsigned)cdiv64(M, rows_per_block));
+  const int nblk = (int)cdiv64(M, rows_per_block);
+  dim3 grid((unsigned)nblk);
   const size_t shm = 2 * (size_t)D * sizeof(float);
+  // thousands of workgroups atomically adding into the same 2*D words serialise; with a workspace each workgroup stores
+  // its partial dw/db row and a second tiny kernel sums the rows
+  float* part = (workspace && workspace_elems >= (int64_t)nblk * 2 * D && (dw || db)) ? workspace : nullptr;
   if (dtDy == DEMO_BF16)
     hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, grid, dim3(256), shm, s, (const bf16_t*)dy, x, w, mean, rstd, dx,
-                       accumulate_dx, (bf16_t*)dx_bf16, dw, db, M, D, rows_per_block);
+                       accumulate_dx, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block);
   else
     hipLaunchKernelGGL(layernorm_bwd_kernel<float>, grid, dim3(256), shm, s, (const float*)dy, x, w, mean, rstd, dx,
-                       accumulate_dx, (bf16_t*)dx_bf16, dw, db, M, D, rows_per_block);
+                       accumulate_dx, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block);
   DEMO_LAUNCH_CHECK("demo_layernorm_bwd");
+  if (part) {
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv64(2 * D, 256), (unsigned)(nblk >= 64 ? 32 : 1)), dim3(256), 0, s, part,
+                       nblk, D, dw, db);
+    DEMO_LAUNCH_CHECK("demo_layernorm_bwd(reduce)");
+  }
   return 0;
 }
+
+extern "C" int64_t demo_layernorm_bwd_workspace(int32_t M, int32_t D) { return cdiv64(M, 16) * 2 * (int64_t)D; }
 
 extern "C" int demo_batchnorm_fwd(const float* x, const float* w, const float* b, float* running_mean, float* running_var,
                                   int32_t training, float momentum, float eps, void* y, int32_t dtY, float* save_mean,

@@ -185,9 +185,9 @@ def atmoe_forward(m, feats: Tensor, B: int, training: bool, tape: Optional[Tape]
     P, S = m.ptab, m.stab
     dev = feats.device
     gk = "generalFusion.moe.gating_network.gate."
-    x1 = ops.gemm(feats.view(B, 7 * C), P.f(gk + "linear_re.0.weight"), bias=P.f(gk + "linear_re.0.bias"), act=ACT_QUICKGELU,
-                  pre_out_new=tape is not None)
-    x1, x1_pre = x1 if tape is not None else (x1, None)
+    # (B, 7C) x (7C, C): a skinny product with a long reduction -> runs split-K (linear epilogue), activation applied after
+    x1_pre = ops.gemm(feats.view(B, 7 * C), P.f(gk + "linear_re.0.weight"), bias=P.f(gk + "linear_re.0.bias"))
+    x1 = ops.act_fwd(x1_pre, ACT_QUICKGELU)
     bn1 = ops.batchnorm_fwd(x1, P.f(gk + "linear_re.2.weight"), P.f(gk + "linear_re.2.bias"), S.f(gk + "linear_re.2.running_mean"),
                             S.f(gk + "linear_re.2.running_var"), training, g.bn_momentum, g.bn_eps, save=tape is not None)
     x2 = bn1[0] if tape is not None else bn1

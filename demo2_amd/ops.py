@@ -231,10 +231,21 @@ def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, 
         accumulate_dx = False
     if dx_lp is not None:
         assert dx_lp.dtype == torch.bfloat16 and dx_lp.is_contiguous() and dx_lp.shape == x.shape
+    ws, ws_n = None, 0
+    if M >= 1024 and (dw is not None or db is not None):        # partial-row workspace (one per device/shape, reused)
+        lib = _lib.load()
+        ws_n = int(lib.demo_layernorm_bwd_workspace(M, D))
+        key = (x.device, ws_n)
+        ws = _LN_WS.get(key)
+        if ws is None:
+            ws = _LN_WS[key] = torch.empty(ws_n, device=x.device, dtype=torch.float32)
     check(_lib.load().demo_layernorm_bwd(dy.data_ptr(), dt_code(dy.dtype), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                         dx.data_ptr(), int(accumulate_dx), _ptr(dx_lp), _ptr(dw), _ptr(db), M, D, _stream()),
+                                         dx.data_ptr(), int(accumulate_dx), _ptr(dx_lp), _ptr(dw), _ptr(db), _ptr(ws), ws_n, M, D, _stream()),
           "demo_layernorm_bwd")
     return dx
+
+
+_LN_WS = {}
 
 
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, shadow: Optional[Tensor], lr: float, beta1: float, beta2: float, eps: float,
@@ -396,6 +407,14 @@ def embed_tokens_bwd(dpre: Tensor, cam: Optional[Tensor], cam_scale: float, cam_
                                             dt_code(dpatch_dtype), dcls.data_ptr(), dpos.data_ptr(), _ptr(dcam), Bn, n_patch, W, _stream()),
           "demo_embed_tokens_bwd")
     return dpatch
+
+
+def act_fwd(pre: Tensor, kind: int, out: Optional[Tensor] = None) -> Tensor:
+    _req_cuda(pre)
+    assert pre.dtype == torch.float32 and pre.is_contiguous()
+    out = torch.empty_like(pre) if out is None else out
+    check(_lib.load().demo_act_fwd(pre.data_ptr(), kind, out.data_ptr(), pre.numel(), _stream()), "demo_act_fwd")
+    return out
 
 
 def act_bwd(dy: Tensor, pre: Tensor, kind: int, out: Optional[Tensor] = None) -> Tensor:

@@ -102,7 +102,11 @@ int demo_layernorm_fwd(const float* x, const float* w, const float* b, float eps
 /* dx (fp32, optionally accumulated into: the residual-stream gradient) from dy (dtype dtDy); dw/db are accumulated into
  * (atomics); dx_bf16 (optional) receives a bf16 copy of the final dx = the A operand of the next backward GEMM. */
 int demo_layernorm_bwd(const void* dy, int32_t dtDy, const float* x, const float* w, const float* mean, const float* rstd,
-                       float* dx, int32_t accumulate_dx, void* dx_bf16, float* dw, float* db, int32_t M, int32_t D, void* stream);
+                       float* dx, int32_t accumulate_dx, void* dx_bf16, float* dw, float* db, float* workspace,
+                       int64_t workspace_elems, int32_t M, int32_t D, void* stream);
+/* workspace (optional, fp32, >= demo_layernorm_bwd_workspace(M, D) elements): per-workgroup dw/db partial rows summed by a
+ * second kernel instead of contended global atomics. */
+int64_t demo_layernorm_bwd_workspace(int32_t M, int32_t D);
 
 /* BatchNorm1d over x (Bn, F) fp32 (nn.BatchNorm1d at AttnMOE.py:30,53; make_model.py:136,176).
  * training!=0: batch statistics (biased var), running stats updated in place with `momentum`
@@ -174,6 +178,8 @@ int demo_attention_bwd(const void* qkv, const void* out, const void* dout, const
  * dpatch (dtype dt_patch) = rows 1.., dcls += sum_b row 0, dpos[t] += sum_b row t, dcam[cam[b]] += cam_scale * rows. */
 int demo_embed_tokens_bwd(const float* dpre, const int64_t* cam, float cam_scale, int32_t cam_all_tokens, void* dpatch,
                           int32_t dt_patch, float* dcls, float* dpos, float* dcam, int32_t Bn, int32_t np, int32_t W, void* stream);
+/* y = act(pre), fp32, n elements (used where the product itself ran split-K and could not apply the activation) */
+int demo_act_fwd(const float* pre, int32_t kind, float* y, int64_t n, void* stream);
 /* dx = dy * act'(pre), fp32, n elements */
 int demo_act_bwd(const float* dy, const float* pre, int32_t kind, float* dx, int64_t n, void* stream);
 /* BatchNorm1d backward with batch statistics (same grouping / gate conventions as demo_batchnorm_fwd);

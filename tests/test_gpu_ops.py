@@ -116,7 +116,7 @@ def test_layernorm_fwd(M, D, dt):
     torch.testing.assert_close(rstd.cpu(), (x.var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("M,D", [(300, 768), (9, 128)])
+@pytest.mark.parametrize("M,D", [(300, 768), (9, 128), (2500, 768)])       # M >= 1024 takes the two-stage dw/db reduction
 def test_layernorm_bwd(M, D):
     x = (rnd(M, D) + 0.3).requires_grad_(True)
     w, b = (1 + rnd(D, seed=1, scale=0.1)).requires_grad_(True), rnd(D, seed=2, scale=0.1).requires_grad_(True)
