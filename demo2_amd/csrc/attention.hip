@@ -1,8 +1,8 @@
-// ViT self-attention for short sequences (L <= 144: 128 patches + cls = 129), head dim 64.
+// ViT self-attention for short sequences (L <= 160: 128 patches + cls = 129), head dim 64.
 //
-// bf16 kernel: one 192-thread workgroup (3 waves) per (image, head).  Q, K, V of that head live
-// entirely in LDS (144/160/160 rows x 128 B = 58 KiB), no tiling over keys and no online
-// rescaling is needed.  Each wave owns 3 query tiles of 16 rows.
+// bf16 kernel: one 256-thread workgroup (4 waves) per (image, head).  Q, K, V of that head live
+// entirely in LDS (3 x 160 rows x 128 B = 60 KiB, two workgroups per CU), no tiling over keys and no online
+// rescaling is needed.  The 10 query tiles of 16 rows are dealt to the 4 waves.
 //   S^T = K Q^T   via v_mfma_f32_16x16x32_bf16 with K rows as the A operand, so that a lane
 //                 holds ONE query (its column) and 4 keys per tile in registers: the softmax
 //                 row reductions are register maxima/sums plus two cross-lane shuffles;
@@ -20,10 +20,10 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
-constexpr int QROWS = 144, KROWS = 160;
+constexpr int QROWS = 160, KROWS = 160;
 constexpr int Q_BYTES = QROWS * 128, K_BYTES = KROWS * 128;
 
-__global__ __launch_bounds__(192, 2) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                float* __restrict__ lse, int L, int H, float scale) {
   __shared__ __attribute__((aligned(1024))) char smem[Q_BYTES + 2 * K_BYTES];
   char* Qs = smem;
@@ -35,22 +35,29 @@ __global__ __launch_bounds__(192, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
   const int64_t ld = 3 * (int64_t)D;
   const bf16_t* base = qkv + (int64_t)b * L * ld + h * 64;
 
-  // ---- stage Q, K, V (zero padded) into LDS, 16 B per thread per step ----------------------
-  constexpr int NCH = (QROWS + 2 * KROWS) * 8;
-  for (int idx = threadIdx.x; idx < NCH; idx += 192) {
-    int which, r;
-    const int c = idx & 7;
-    const int rowi = idx >> 3;
-    if (rowi < QROWS) { which = 0; r = rowi; }
-    else if (rowi < QROWS + KROWS) { which = 1; r = rowi - QROWS; }
-    else { which = 2; r = rowi - QROWS - KROWS; }
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (r < L) v = *reinterpret_cast<const uint4*>(base + (int64_t)r * ld + which * D + c * 8);
-    char* dst;
-    if (which == 0) dst = Qs + r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
-    else if (which == 1) dst = Ks + r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
-    else dst = Vs + r * 128 + ((c ^ (r & 6)) << 4);
-    *reinterpret_cast<uint4*>(dst) = v;
+  // ---- stage Q, K, V (zero padded to 160 rows): all 15 global loads of a thread are issued before the first LDS
+  //      write, so the HBM latency is paid once per workgroup instead of once per 16-B chunk ----------------------
+  {
+    uint4 vq[5], vk[5], vv[5];
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+      const int idx = threadIdx.x + it * 256, r = idx >> 3, c = idx & 7;
+      vq[it] = vk[it] = vv[it] = make_uint4(0u, 0u, 0u, 0u);
+      if (r < L) {
+        const bf16_t* p = base + (int64_t)r * ld + c * 8;
+        vq[it] = *reinterpret_cast<const uint4*>(p);
+        vk[it] = *reinterpret_cast<const uint4*>(p + D);
+        vv[it] = *reinterpret_cast<const uint4*>(p + 2 * D);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+      const int idx = threadIdx.x + it * 256, r = idx >> 3, c = idx & 7;
+      const int oqk = r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
+      *reinterpret_cast<uint4*>(Qs + oqk) = vq[it];
+      *reinterpret_cast<uint4*>(Ks + oqk) = vk[it];
+      *reinterpret_cast<uint4*>(Vs + r * 128 + ((c ^ (r & 6)) << 4)) = vv[it];
+    }
   }
   __syncthreads();
 
@@ -71,8 +78,8 @@ __global__ __launch_bounds__(192, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
   const float c2 = scale * 1.4426950408889634f;   // softmax in base 2
 
   for (int qq = 0; qq < 3; ++qq) {
-    const int qt = wave * 3 + qq;
-    if (qt * 16 >= L) break;                       // wave-uniform
+    const int qt = wave + 4 * qq;                  // 10 query tiles over 4 waves: {0,4,8} {1,5,9} {2,6} {3,7}
+    if (qt * 16 >= L || qt >= 10) break;           // wave-uniform
     const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(Qs + qt * 2048 + fo0);
     const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(Qs + qt * 2048 + fo1);
 
@@ -215,7 +222,7 @@ extern "C" int demo_attention_fwd(const void* qkv, void* out, float* lse, int32_
   hipStream_t s = (hipStream_t)stream;
   const float scale = 0.125f;
   if (dt == DEMO_BF16 && L <= QROWS && (((uintptr_t)qkv & 15) == 0) && (((uintptr_t)out & 7) == 0)) {
-    hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(Bn * H), dim3(192), 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, scale);
+    hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(Bn * H), dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, L, H, scale);
   } else {
     const size_t shm = sizeof(float) * ((size_t)L * 65 + (size_t)L * 64 + 4 * (size_t)L + 4 * 64);
     if (shm > 48 * 1024) {   // opt in to the large-LDS carve-out (160 KiB per CU on gfx950)

@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 // Backward: one wave per row for dx; dw/db accumulated per block in LDS then atomically added
 // into fp32 dw/db (D floats each; D*gridDim atomics spread over D addresses).
-template <typename TDY>
+// NV = float4 per lane (compile time: D = 768 -> 3), so that only the registers a row needs are allocated and 8 waves per
+// SIMD hide the HBM latency of this pure streaming kernel.
+template <typename TDY, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ w, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dx,
@@ -74,9 +76,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nv = D >> 2;
   const int r0 = blockIdx.x * rows_per_block;
-  float4 adw[LN_MAXV], adb[LN_MAXV];
+  float4 adw[NV], adb[NV];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) adw[i] = adb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < NV; ++i) adw[i] = adb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   for (int rr = wv; rr < rows_per_block; rr += 4) {
     const int row = r0 + rr;
@@ -84,10 +86,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
     const float mu = mean[row], rs = rstd[row];
     const float* xr = x + (int64_t)row * D;
     const TDY* dyr = dy + (int64_t)row * D;
-    float4 xh[LN_MAXV], g[LN_MAXV];
+    float4 xh[NV], g[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + i * 64;
       if (c < nv) {
         const float4 xv = *reinterpret_cast<const float4*>(xr + c * 4);
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
     s2 = wave_sum(s2) / (float)D;
     float* dxr = dx + (int64_t)row * D;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + i * 64;
       if (c < nv) {
         float4 o;
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
     }
   }
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane + i * 64;
     if (c < nv) {
       atomicAdd(&s_dw[c * 4 + 0], adw[i].x); atomicAdd(&s_dw[c * 4 + 1], adw[i].y);
@@ -240,12 +242,23 @@ extern "C" int demo_layernorm_bwd(const void* dy, int32_t dtDy, const float* x, 
   // thousands of workgroups atomically adding into the same 2*D words serialise; with a workspace each workgroup stores
   // its partial dw/db row and a second tiny kernel sums the rows
   float* part = (workspace && workspace_elems >= (int64_t)nblk * 2 * D && (dw || db)) ? workspace : nullptr;
-  if (dtDy == DEMO_BF16)
-    hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, grid, dim3(256), shm, s, (const bf16_t*)dy, x, w, mean, rstd, dx,
-                       accumulate_dx, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block);
-  else
-    hipLaunchKernelGGL(layernorm_bwd_kernel<float>, grid, dim3(256), shm, s, (const float*)dy, x, w, mean, rstd, dx,
-                       accumulate_dx, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block);
+  const int nvl = (int)cdiv64(D, 256);      // float4 per lane actually needed
+#define LN_BWD_LAUNCH(NV_)                                                                                                      \
+  do {                                                                                                                          \
+    if (dtDy == DEMO_BF16)                                                                                                      \
+      hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, NV_>), grid, dim3(256), shm, s, (const bf16_t*)dy, x, w, mean, rstd, dx, \
+                         accumulate_dx, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block);                                  \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((layernorm_bwd_kernel<float, NV_>), grid, dim3(256), shm, s, (const float*)dy, x, w, mean, rstd, dx,   \
+                         accumulate_dx, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block);                                  \
+  } while (0)
+  if (nvl <= 1) LN_BWD_LAUNCH(1);
+  else if (nvl <= 2) LN_BWD_LAUNCH(2);
+  else if (nvl <= 3) LN_BWD_LAUNCH(3);
+  else if (nvl <= 4) LN_BWD_LAUNCH(4);
+  else if (nvl <= 6) LN_BWD_LAUNCH(6);
+  else LN_BWD_LAUNCH(8);
+#undef LN_BWD_LAUNCH
   DEMO_LAUNCH_CHECK("demo_layernorm_bwd");
   if (part) {
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv64(2 * D, 256), (unsigned)(nblk >= 64 ? 32 : 1)), dim3(256), 0, s, part,
