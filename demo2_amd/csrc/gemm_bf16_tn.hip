@@ -34,6 +34,7 @@ struct TArgs {
   int splitk, kper;     // kper = reduction rows per split (multiple of BK)
   float alpha;
   int ntm, ntn;
+  int part_m;           // 1: XCDs partition the Mo panels, 0: the No panels
   int use_atomics;      // 1: atomicAdd into C; 0: C = (accumulate ? C : 0) + result with plain stores
   int accumulate;
   float* colsum;        // optional: colsum[m] += sum_r A[r, m]  (the bias gradient of the same Linear), atomics
@@ -64,36 +65,25 @@ __device__ __forceinline__ void stage_tile_tail(const bf16_t* __restrict__ G, in
   }
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const TArgs p) {
-  __shared__ __attribute__((aligned(1024))) char smem[2 * BUF_BYTES];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int tile = blockIdx.x;
-  const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int ks = blockIdx.y * p.kper;
-  const int ke = min(p.Kr, ks + p.kper);
-  if (ks >= ke) return;
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // bias gradient for free: the waves that own the first column panel also multiply their A fragments by a fragment
-  // of ones, which leaves sum_r A[r, m] in every column of a 16x16 accumulator (4 extra MFMAs per 32-deep step)
-  const bool do_colsum = p.colsum != nullptr && tn == 0 && wc == 0;          // wave-uniform
-  f32x4 csum[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) csum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
-
+// K-loop.  CS = this wave also accumulates the bias gradient: its A fragments times a fragment of ones leave sum_r A[r, m]
+// in every column of a 16x16 accumulator (4 extra MFMAs per 32-deep step).  CS is a template parameter and the choice is
+// made ONCE outside the loop: a wave-uniform `if` around MFMAs inside the loop made hipcc copy all 64 accumulator
+// registers every iteration (68 v_mov per K-step).
+template <bool CS>
+__device__ __forceinline__ void tn_mainloop(const TArgs& p, char* smem, f32x4 (&acc)[4][4], f32x4 (&csum)[4], int m0, int n0, int ks,
+                                            int ke, int wave, int lane, int wr, int wc) {
   // transposed-read addressing: lane (g, idx=4q+pp): row 8g+q (+4), 8-B piece at column 4*pp of a 16-column block
   const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
-  const int trow = 8 * g + q;                         // row inside a 32-row k-step (first read); second read = +4
-  const int sw0 = (q << 1) | ((g & 1) << 3), sw1 = sw0;  // swizzle of row 8g+q and of row 8g+q+4 (bit 2 of the row is not used)
+  const int trow = 8 * g + q;                         // row inside a 32-row k-step (first read); second read = +4 rows
+  const int sw = (q << 1) | ((g & 1) << 3);           // chunk swizzle of rows 8g+q and 8g+q+4
   const int half = (pp & 1) << 3, csub = pp >> 1;
+  int aoff[4], boff[4];                                // per-lane byte offsets inside an operand tile (k-step 0, first read)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    aoff[i] = trow * 256 + (((wr * 8 + i * 2 + csub) ^ sw) << 4) + half;
+    boff[i] = trow * 256 + (((wc * 8 + i * 2 + csub) ^ sw) << 4) + half;
+  }
+  const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
   const int nk = (ke - ks + BK - 1) / BK;
   auto stage = [&](int t, char* buf) {
@@ -117,28 +107,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const TArgs p) {
     const char* lb = cur + TILE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      const int rbase = (kk * 32 + trow) * 256;
       bf16x8 af[4], bfr[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int c = wr * 8 + i * 2 + csub;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(la + rbase + ((c ^ sw0) << 4) + half));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(la + rbase + 1024 + ((c ^ sw1) << 4) + half));
-        af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(la + kk * 8192 + aoff[i]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(la + kk * 8192 + 1024 + aoff[i]));
+        af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int c = wc * 8 + j * 2 + csub;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lb + rbase + ((c ^ sw0) << 4) + half));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lb + rbase + 1024 + ((c ^ sw1) << 4) + half));
-        bfr[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lb + kk * 8192 + boff[j]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lb + kk * 8192 + 1024 + boff[j]));
+        bfr[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-      if (do_colsum) {
+      if constexpr (CS) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) csum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, csum[i], 0, 0, 0);
       }
@@ -146,6 +133,41 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const TArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const TArgs p) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * BUF_BYTES];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  // XCD-aware work map.  Both operands are streamed (tokens x features), each column panel is shared by every tile of
+  // the other dimension.  Workgroup ids are dealt round-robin to the 8 XCDs (private L2s): XCD x owns the panels
+  // x, x+8, ... of the dimension with MORE panels (the bigger operand), so that operand crosses the fabric once
+  // instead of 8 times; inside an XCD the order is split-major so co-resident workgroups walk the same token rows.
+  const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
+  const int P = p.part_m ? p.ntm : p.ntn, Q = p.part_m ? p.ntn : p.ntm;
+  const int np = (P - xcd + 7) >> 3;                  // panels owned by this XCD
+  if (w >= np * Q * p.splitk) return;                 // padding workgroups (P not a multiple of 8)
+  const int split = w / (np * Q), rem = w - split * (np * Q);
+  const int pidx = xcd + 8 * (rem / Q), qidx = rem % Q;
+  const int tm = p.part_m ? pidx : qidx, tn = p.part_m ? qidx : pidx;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int ks = split * p.kper;
+  const int ke = min(p.Kr, ks + p.kper);
+  if (ks >= ke) return;
+
+  f32x4 acc[4][4], csum[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    csum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  // bias gradient: only the waves that own the first column panel (tn == 0, wc == 0) carry it
+  const bool do_colsum = p.colsum != nullptr && tn == 0 && wc == 0;          // wave-uniform
+  if (do_colsum) tn_mainloop<true>(p, smem, acc, csum, m0, n0, ks, ke, wave, lane, wr, wc);
+  else tn_mainloop<false>(p, smem, acc, csum, m0, n0, ks, ke, wave, lane, wr, wc);
+  const int g = lane >> 4, idx = lane & 15;
 
   if (do_colsum && idx == 0) {
 #pragma unroll
@@ -201,7 +223,10 @@ extern "C" int demo_gemm_tn_bf16(const void* A, const void* B, float* C, int32_t
     hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)No * sizeof(float), (size_t)Mo, s);
     if (e != hipSuccess) DEMO_FAIL(-2, "demo_gemm_tn_bf16: memset failed: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3((unsigned)tiles, (unsigned)p.splitk), dim3(256), 0, s, p);
+  p.part_m = p.ntm >= p.ntn;
+  const int Pp = p.part_m ? p.ntm : p.ntn, Qq = p.part_m ? p.ntn : p.ntm;
+  const unsigned nwg = 8u * (unsigned)(((Pp + 7) / 8) * Qq * p.splitk);
+  hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3(nwg), dim3(256), 0, s, p);
   DEMO_LAUNCH_CHECK("demo_gemm_tn_bf16");
   return 0;
 }
