@@ -49,6 +49,7 @@ PROTOTYPES = {
     "demo_cast_f32_bf16": [_P, _P, _L, _P],
     "demo_cast_bf16_f32": [_P, _P, _L, _P],
     "demo_transpose": [_P, _P, _I, _I, _I, _P],
+    "demo_transpose_batched": [_P, _P, _I, _I, _I, _L, _L, _I, _P],
     "demo_colsum": [_P, _P, _I, _I, _L, _I, _I, _P],
     "demo_im2col": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "demo_embed_tokens": [_P, _I, _P, _P, _P, _P, _F, _I, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P],

@@ -95,6 +95,81 @@ __global__ __launch_bounds__(64) void batchnorm_bwd_kernel(const float* __restri
   }
 }
 
+// Sliced form for Bn <= 128 (the training batch): workgroup = 64 features x 4 row slices, every x / dy value of the slice is
+// loaded once into registers (all loads in flight together instead of Bn serial latencies per thread), the per-feature
+// sums cross the 4 waves through LDS.  The gate gradient is reduced over the wave's 64 features first, so a (row, group)
+// word receives gsz/64 atomics instead of gsz.
+__global__ __launch_bounds__(256) void batchnorm_bwd_sliced_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                   const float* __restrict__ w, const float* __restrict__ b,
+                                                                   const float* __restrict__ save_mean,
+                                                                   const float* __restrict__ save_invstd, float* __restrict__ dx,
+                                                                   int accumulate_dx, float* __restrict__ dw, float* __restrict__ db,
+                                                                   int Bn, int F, int gsz, int n_inner, int n_outer, int64_t pstride,
+                                                                   const float* __restrict__ gate, float* __restrict__ dgate) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + lane;
+  const bool fok = f < F;
+  const int fc = fok ? f : F - 1;
+  int64_t pi = fc;
+  int gi = 0, go = 0;
+  if (gsz > 0) {
+    const int g = fc / gsz, k = fc - g * gsz;
+    gi = g % n_inner; go = g / n_inner;
+    pi = ((int64_t)gi * n_outer + go) * pstride + k;
+  }
+  const float mean = save_mean[fc], invstd = save_invstd[fc], wv_ = w[pi], bv = b ? b[pi] : 0.f;
+  const bool wave_one_group = gsz > 0 && gsz % 64 == 0;
+  float xh[32], d[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int r = wv + 4 * i;
+    const bool ok = fok && r < Bn;
+    xh[i] = ok ? x[(int64_t)r * F + f] : mean;
+    d[i] = ok ? dy[(int64_t)r * F + f] : 0.f;
+  }
+  float sdy = 0.f, sdyx = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int r = wv + 4 * i;
+    xh[i] = (xh[i] - mean) * invstd;
+    if (gate && r < Bn) {                                   // r < Bn is wave-uniform
+      const int64_t gidx = ((int64_t)r * n_inner + gi) * n_outer + go;
+      if (dgate) {
+        const float gv = d[i] * (xh[i] * wv_ + bv);
+        if (wave_one_group) {
+          const float t = wave_sum(gv);
+          if (lane == 0) atomicAdd(&dgate[gidx], t);
+        } else if (fok) {
+          atomicAdd(&dgate[gidx], gv);
+        }
+      }
+      d[i] *= gate[gidx];
+    }
+    sdy += d[i];
+    sdyx += d[i] * xh[i];
+  }
+  red[0][wv][lane] = sdy;
+  red[1][wv][lane] = sdyx;
+  __syncthreads();
+  sdy = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+  sdyx = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+  if (wv == 0 && fok) {
+    if (dw) dw[pi] += sdyx;
+    if (db) db[pi] += sdy;
+  }
+  const float inv = 1.f / (float)Bn;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int r = wv + 4 * i;
+    if (fok && r < Bn) {
+      float v = wv_ * invstd * (d[i] - sdy * inv - xh[i] * sdyx * inv);
+      if (accumulate_dx) v += dx[(int64_t)r * F + f];
+      dx[(int64_t)r * F + f] = v;
+    }
+  }
+}
+
 // ---- ATMoE gate softmax backward: block per sample, wave per head ---------------------------------------------------
 __global__ __launch_bounds__(256) void atmoe_gate_softmax_bwd_kernel(const float* __restrict__ dgates, const float* __restrict__ gates,
                                                                      const float* __restrict__ q, const float* __restrict__ k,
@@ -166,47 +241,128 @@ __global__ __launch_bounds__(256) void hdm_softmax_pool_bwd_kernel(const float* 
   __syncthreads();
   const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   const uint32_t thresh = p_drop > 0.f ? (uint32_t)(p_drop * 4294967296.0) : 0u;
-  const int nper = (C + 63) / 64;           // channels per lane (<= 16 for C <= 1024)
-  for (int l = wave; l < L; l += 4) {
-    const int64_t row = (int64_t)(m * Bs + b) * L + l;
-    float xv[16], dxv[16];
+  // Lane roles: for the dot products / dx a lane owns channel quads (i*64 + lane)*4; for dS a lane owns score columns
+  // lane and lane + 64 (column = branch*Hh + head; 7*Hh <= 84).  Everything a column needs that does not depend on the
+  // token is fetched once here; per token the column's probability is ONE coalesced load issued with the token's x row
+  // (the earlier form loaded it inside the (branch, head) loop: 16 dependent HBM latencies per token).
+  const int nch = (C + 255) / 256;
+  const int ncol = 7 * Hh;
+  int col_s[2];
+  float col_rd[2], col_dps[2];
+  int64_t col_pbase[2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c = lane + i * 64;
-      xv[i] = (i < nper && c < C) ? io<T>::ld(tok + row * C + c) : 0.f;
-      dxv[i] = 0.f;
+  for (int k = 0; k < 2; ++k) {
+    const int col = lane + 64 * k;
+    col_s[k] = -1;
+    col_rd[k] = col_dps[k] = 0.f;
+    col_pbase[k] = 0;
+    if (col < ncol) {
+      const int br = col / Hh, h = col - br * Hh;
+#pragma unroll
+      for (int ss = 0; ss < 4; ++ss)
+        if (b_mbranch[m][ss] == br) {
+          col_s[k] = ss;
+          col_rd[k] = rowdot[ss * HH_MAX + h];
+          col_dps[k] = dps[ss * HH_MAX + h];
+          col_pbase[k] = ((int64_t)(b * 7 + br) * Hh + h) * L3 + (int64_t)b_mpos[m][ss] * L;
+        }
     }
-    float* dsrow = dS + row * ldS;
-    for (int c = lane; c < ldS; c += 64) dsrow[c] = 0.f;      // columns of branches that do not attend this modality
-    __builtin_amdgcn_wave_barrier();
+  }
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int l0 = wave * 2; l0 < L; l0 += 8) {          // two tokens per wave per pass: each dpooled row read serves both
+    const bool has2 = l0 + 1 < L;
+    const int64_t row0 = (int64_t)(m * Bs + b) * L + l0;
+    float4 x0[4], x1[4], dx0[4], dx1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c4 = (i * 64 + lane) * 4;
+      const bool in = i < nch && c4 < C;
+      x0[i] = in ? io<T>::ld4(tok + row0 * C + c4) : zero4;
+      x1[i] = (in && has2) ? io<T>::ld4(tok + (row0 + 1) * C + c4) : zero4;
+      dx0[i] = dx1[i] = zero4;
+    }
+    float p0[2], p1[2], a0[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      p0[k] = col_s[k] >= 0 ? probs[col_pbase[k] + l0] : 0.f;
+      p1[k] = (col_s[k] >= 0 && has2) ? probs[col_pbase[k] + l0 + 1] : 0.f;
+    }
+#pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int br = b_mbranch[m][s];
-      const int lk = b_mpos[m][s] * L + l;
+      const int cb = b_mbranch[m][s] * Hh;
       for (int h = 0; h < Hh; ++h) {
         const float* dp_h = dpl + (s * Hh + h) * C;
-        float a = 0.f;
+        float d0 = 0.f, d1 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int c = lane + i * 64;
-          if (i < nper && c < C) a = fmaf(dp_h[c], xv[i], a);
+        for (int i = 0; i < 4; ++i) {
+          const int c4 = (i * 64 + lane) * 4;
+          if (i < nch && c4 < C) {
+            const float4 wv = *reinterpret_cast<const float4*>(dp_h + c4);
+            d0 += (wv.x * x0[i].x + wv.y * x0[i].y) + (wv.z * x0[i].z + wv.w * x0[i].w);
+            d1 += (wv.x * x1[i].x + wv.y * x1[i].y) + (wv.z * x1[i].z + wv.w * x1[i].w);
+          }
         }
-        a = wave_sum(a) + dps[s * HH_MAX + h];                 // dP_l
-        const int64_t pidx = ((int64_t)(b * 7 + br) * Hh + h) * L3 + lk;
-        const float p = probs[pidx];
-        float P = p;
-        if (p_drop > 0.f) P = (rng_hash(seed, (uint64_t)pidx) >= thresh) ? p * keep_scale : 0.f;
-        if (lane == 0) dsrow[br * Hh + h] = P * a - p * rowdot[s * HH_MAX + h];
+        d0 = wave_sum(d0);
+        d1 = wave_sum(d1);
+        const int col = cb + h;                        // wave-uniform
+        if (col < 64) { if (lane == col) { a0[0] = d0; a1[0] = d1; } }
+        else if (lane == col - 64) { a0[1] = d0; a1[1] = d1; }
+      }
+    }
+    // dS columns of this lane for both tokens (columns of branches that do not attend this modality are zero)
+    float P0[2], P1[2];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int c = lane + i * 64;
-          if (i < nper && c < C) dxv[i] = fmaf(P, dp_h[c], dxv[i]);
+    for (int k = 0; k < 2; ++k) {
+      const int col = lane + 64 * k;
+      float ds0 = 0.f, ds1 = 0.f;
+      P0[k] = P1[k] = 0.f;
+      if (col_s[k] >= 0) {
+        P0[k] = p0[k];
+        P1[k] = p1[k];
+        if (p_drop > 0.f) {
+          P0[k] = (rng_hash(seed, (uint64_t)(col_pbase[k] + l0)) >= thresh) ? p0[k] * keep_scale : 0.f;
+          P1[k] = (rng_hash(seed, (uint64_t)(col_pbase[k] + l0 + 1)) >= thresh) ? p1[k] * keep_scale : 0.f;
+        }
+        ds0 = P0[k] * (a0[k] + col_dps[k]) - p0[k] * col_rd[k];
+        ds1 = P1[k] * (a1[k] + col_dps[k]) - p1[k] * col_rd[k];
+      }
+      if (col < ldS) {
+        dS[row0 * ldS + col] = ds0;
+        if (has2) dS[(row0 + 1) * ldS + col] = ds1;
+      }
+    }
+    for (int c = lane + 128; c < ldS; c += 64) {
+      dS[row0 * ldS + c] = 0.f;
+      if (has2) dS[(row0 + 1) * ldS + c] = 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int cb = b_mbranch[m][s] * Hh;
+      for (int h = 0; h < Hh; ++h) {
+        const float* dp_h = dpl + (s * Hh + h) * C;
+        const int col = cb + h;
+        const float Pa = col < 64 ? lane_value(P0[0], col) : lane_value(P0[1], col - 64);
+        const float Pb = col < 64 ? lane_value(P1[0], col) : lane_value(P1[1], col - 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c4 = (i * 64 + lane) * 4;
+          if (i < nch && c4 < C) {
+            const float4 wv = *reinterpret_cast<const float4*>(dp_h + c4);
+            dx0[i].x = fmaf(Pa, wv.x, dx0[i].x); dx0[i].y = fmaf(Pa, wv.y, dx0[i].y);
+            dx0[i].z = fmaf(Pa, wv.z, dx0[i].z); dx0[i].w = fmaf(Pa, wv.w, dx0[i].w);
+            dx1[i].x = fmaf(Pb, wv.x, dx1[i].x); dx1[i].y = fmaf(Pb, wv.y, dx1[i].y);
+            dx1[i].z = fmaf(Pb, wv.z, dx1[i].z); dx1[i].w = fmaf(Pb, wv.w, dx1[i].w);
+          }
         }
       }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c = lane + i * 64;
-      if (i < nper && c < C) dtok[row * C + c] = dxv[i];
+    for (int i = 0; i < 4; ++i) {
+      const int c4 = (i * 64 + lane) * 4;
+      if (i < nch && c4 < C) {
+        *reinterpret_cast<float4*>(dtok + row0 * C + c4) = dx0[i];
+        if (has2) *reinterpret_cast<float4*>(dtok + (row0 + 1) * C + c4) = dx1[i];
+      }
     }
   }
 }
@@ -352,8 +508,12 @@ extern "C" int demo_batchnorm_bwd(const float* dy, const float* x, const float* 
                                   float* dgate, void* stream) {
   DEMO_REQUIRE(gsz == 0 || (F % gsz == 0 && (F / gsz) == n_inner * n_outer), "demo_batchnorm_bwd: bad grouping");
   DEMO_REQUIRE(!gate || (gsz > 0 && b), "demo_batchnorm_bwd: gate requires grouping and the bias");
-  hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3((unsigned)cdiv64(F, 64)), dim3(64), 0, (hipStream_t)stream, dy, x, w, b, save_mean,
-                     save_invstd, dx, accumulate_dx, dw, db, Bn, F, gsz, n_inner, n_outer, pstride, gate, dgate);
+  if (Bn <= 128)
+    hipLaunchKernelGGL(batchnorm_bwd_sliced_kernel, dim3((unsigned)cdiv64(F, 64)), dim3(256), 0, (hipStream_t)stream, dy, x, w, b,
+                       save_mean, save_invstd, dx, accumulate_dx, dw, db, Bn, F, gsz, n_inner, n_outer, pstride, gate, dgate);
+  else
+    hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3((unsigned)cdiv64(F, 64)), dim3(64), 0, (hipStream_t)stream, dy, x, w, b, save_mean,
+                       save_invstd, dx, accumulate_dx, dw, db, Bn, F, gsz, n_inner, n_outer, pstride, gate, dgate);
   DEMO_LAUNCH_CHECK("demo_batchnorm_bwd");
   return 0;
 }
@@ -368,7 +528,7 @@ extern "C" int demo_atmoe_gate_softmax_bwd(const float* dgates, const float* gat
 extern "C" int demo_hdm_softmax_pool_bwd(const float* dpooled, const float* dpsum, const float* probs, const void* tokens, int32_t dt,
                                          const float* pooled, const float* psum, float* dS, int64_t ldS, float* dtokens, int32_t Bs,
                                          int32_t L, int32_t C, int32_t Hh, float p_drop, uint64_t seed, void* stream) {
-  DEMO_REQUIRE(Hh >= 1 && Hh <= HH_MAX && C <= 1024 && ldS >= 7 * Hh, "demo_hdm_softmax_pool_bwd: unsupported shape");
+  DEMO_REQUIRE(Hh >= 1 && Hh <= HH_MAX && C <= 1024 && C % 4 == 0 && ldS >= 7 * Hh, "demo_hdm_softmax_pool_bwd: unsupported shape");
   const size_t shm = sizeof(float) * (4 * (size_t)Hh * C + 8 * HH_MAX);
   DEMO_REQUIRE(shm <= 160 * 1024, "demo_hdm_softmax_pool_bwd: needs %zu B of LDS", shm);
   hipStream_t s = (hipStream_t)stream;

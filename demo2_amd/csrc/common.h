@@ -45,12 +45,22 @@ template <> struct io<float> {
   static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
   static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
   static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+  // raw4: the 4 elements as loaded (conversion deferred, so a prefetched value can sit in registers untouched)
+  typedef float4 raw4;
+  static __device__ __forceinline__ raw4 ld4_raw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ float4 cvt4(raw4 r) { return r; }
 };
 template <> struct io<bf16_t> {
   static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
   static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
   static __device__ __forceinline__ float4 ld4(const bf16_t* p) {
     uint2 r = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                       __uint_as_float(r.y & 0xffff0000u));
+  }
+  typedef uint2 raw4;
+  static __device__ __forceinline__ raw4 ld4_raw(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+  static __device__ __forceinline__ float4 cvt4(raw4 r) {
     return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
                        __uint_as_float(r.y & 0xffff0000u));
   }
@@ -63,15 +73,28 @@ template <> struct io<bf16_t> {
 };
 
 // ---- wave reductions (64 lanes) -----------------------------------------------------------------
+// Wave-wide reductions on the VALU's DPP data path (no LDS round trips as with ds_bpermute shuffles): quad swap,
+// quad-pair swap, half-row mirror, row mirror leave every lane of a 16-lane row with the row's value; the four rows are
+// combined through v_readlane, so the result is wave-uniform.  All 64 lanes must be active at the call.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_value(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);    // row_half_mirror
+  v += dpp_mov<0x140>(v);    // row_mirror
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
+  return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
 // ---- activations ---------------------------------------------------------------------------------

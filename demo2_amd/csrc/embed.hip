@@ -151,8 +151,11 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __rest
 
 // 64x64 LDS-tiled transpose
 template <typename T>
-__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int rows, int cols) {
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, T* __restrict__ dst, int rows, int cols,
+                                                        int64_t src_stride, int64_t dst_stride) {
   __shared__ T tile[64][65];
+  src += blockIdx.z * src_stride;          // batch of equally shaped matrices (the per-layer weights of one kind)
+  dst += blockIdx.z * dst_stride;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int i = ty; i < 64; i += 4) {
@@ -261,13 +264,21 @@ extern "C" int demo_cast_bf16_f32(const void* src, float* dst, int64_t n, void* 
   return 0;
 }
 
-extern "C" int demo_transpose(const void* src, void* dst, int32_t rows, int32_t cols, int32_t dt, void* stream) {
-  dim3 grid((unsigned)cdiv64(cols, 64), (unsigned)cdiv64(rows, 64));
+extern "C" int demo_transpose_batched(const void* src, void* dst, int32_t rows, int32_t cols, int32_t batch, int64_t src_stride,
+                                      int64_t dst_stride, int32_t dt, void* stream) {
+  DEMO_REQUIRE(rows > 0 && cols > 0 && batch > 0 && batch <= 65535, "demo_transpose: bad shape %d x %d x %d", batch, rows, cols);
+  dim3 grid((unsigned)cdiv64(cols, 64), (unsigned)cdiv64(rows, 64), (unsigned)batch);
   hipStream_t s = (hipStream_t)stream;
-  if (dt == DEMO_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, rows, cols);
-  else hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, s, (const float*)src, (float*)dst, rows, cols);
+  if (dt == DEMO_BF16)
+    hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, rows, cols, src_stride, dst_stride);
+  else
+    hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, s, (const float*)src, (float*)dst, rows, cols, src_stride, dst_stride);
   DEMO_LAUNCH_CHECK("demo_transpose");
   return 0;
+}
+
+extern "C" int demo_transpose(const void* src, void* dst, int32_t rows, int32_t cols, int32_t dt, void* stream) {
+  return demo_transpose_batched(src, dst, rows, cols, 1, 0, 0, dt, stream);
 }
 
 extern "C" int demo_colsum(const void* X, float* out, int32_t M, int32_t N, int64_t ldx, int32_t dt, int32_t accumulate, void* stream) {

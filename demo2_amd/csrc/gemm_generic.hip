@@ -105,6 +105,14 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GArgs args) {
   }
 }
 
+__global__ __launch_bounds__(256) void clear_c_kernel(float* __restrict__ C, int M, int N, int64_t c_rs, int batch2, int64_t sC1,
+                                                      int64_t sC2) {
+  const int z = blockIdx.z;
+  float* c = C + (z / batch2) * sC1 + (z % batch2) * sC2;
+  const int64_t mn = (int64_t)M * N;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < mn; i += (int64_t)gridDim.x * 256) c[(i / N) * c_rs + (i % N)] = 0.f;
+}
+
 template <typename TA, typename TB>
 int launch_c(const demo_gemm_desc& d, hipStream_t s) {
   GArgs a;
@@ -126,10 +134,15 @@ int launch_c(const demo_gemm_desc& d, hipStream_t s) {
       a.kper = per * GK;
       a.splitk = (int)cdiv64(ksteps, per);
       if (!d.accumulate) {                                       // slices add into C: clear it first (rows may be strided)
-        for (int z = 0; z < d.batch1 * d.batch2; ++z) {
-          float* c = reinterpret_cast<float*>(d.C) + (z / d.batch2) * d.sC1 + (z % d.batch2) * d.sC2;
-          hipError_t e = hipMemset2DAsync(c, (size_t)d.c_rs * sizeof(float), 0, (size_t)d.N * sizeof(float), (size_t)d.M, s);
+        const int nb = d.batch1 * d.batch2;
+        if (nb == 1) {
+          hipError_t e = hipMemset2DAsync(d.C, (size_t)d.c_rs * sizeof(float), 0, (size_t)d.N * sizeof(float), (size_t)d.M, s);
           if (e != hipSuccess) DEMO_FAIL(-2, "demo_gemm(generic): memset failed: %s", hipGetErrorString(e));
+        } else {                                                 // one launch for the whole batch, not a memset per matrix
+          const int64_t mn = (int64_t)d.M * d.N;
+          hipLaunchKernelGGL(clear_c_kernel, dim3((unsigned)(cdiv64(mn, 256) < 64 ? cdiv64(mn, 256) : 64), 1, (unsigned)nb), dim3(256),
+                             0, s, reinterpret_cast<float*>(d.C), d.M, d.N, d.c_rs, d.batch2, d.sC1, d.sC2);
+          DEMO_LAUNCH_CHECK("demo_gemm(generic clear)");
         }
       }
     }

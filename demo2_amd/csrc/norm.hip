@@ -57,17 +57,112 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
-// Backward: one wave per row for dx; dw/db accumulated per block in LDS then atomically added
-// into fp32 dw/db (D floats each; D*gridDim atomics spread over D addresses).
+// Backward, column-owner form (D <= 1024): thread t owns columns 4t..4t+3 and walks the workgroup's rows R at a time.
+// All 3R loads of a chunk (x, dy, running dx) are issued back to back, so a wave keeps R*40 B per lane in flight with
+// ~110 VGPRs at R = 4 (4 waves/SIMD; R = 8 at 2 waves/SIMD measures the same); measured loaded-HBM latency is ~5 us, i.e. this kernel lives on bytes in flight.  The two
+// row sums cross the waves through a parity-double-buffered LDS slot (one barrier per chunk).  dw/db are per-thread
+// column accumulators (8 registers, no LDS atomics) stored once per workgroup into the partial-row workspace.
+template <typename TDY, int R, bool ACC>
+__global__ __launch_bounds__(256) void layernorm_bwd_cols_kernel(const TDY* __restrict__ dy, const float* __restrict__ x,
+                                                                 const float* __restrict__ w, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, float* __restrict__ dx,
+                                                                 bf16_t* __restrict__ dx_lp, float* __restrict__ dw,
+                                                                 float* __restrict__ db, float* __restrict__ part, int M, int D,
+                                                                 int rows_per_block) {
+  typedef typename io<TDY>::raw4 dyraw;
+  __shared__ float red[2][R][2][4];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, nw = blockDim.x >> 6;
+  const int c4 = t * 4;
+  const bool colok = c4 < D;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 w4 = colok ? *reinterpret_cast<const float4*>(w + c4) : zero4;
+  float4 adw = zero4, adb = zero4;
+  const float inv_d = 1.f / (float)D;
+  const int r0 = blockIdx.x * rows_per_block;
+  int par = 0;
+  for (int rc = 0; rc < rows_per_block; rc += R, par ^= 1) {
+    const int rbase = r0 + rc;
+    if (rbase >= M) break;
+    float4 xv[R], pv[R];
+    dyraw dv[R];
+    float mu[R], rs[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = rbase + r;
+      const bool rowok = row < M;                       // workgroup-uniform
+      const bool ok = rowok && colok;
+      const int64_t o = (int64_t)row * D;               // uniform row base (SGPR pair) + per-thread 32-bit column offset
+      mu[r] = rowok ? mean[row] : 0.f;
+      rs[r] = rowok ? rstd[row] : 0.f;
+      xv[r] = ok ? *reinterpret_cast<const float4*>((x + o) + c4) : zero4;
+      if (ok) dv[r] = io<TDY>::ld4_raw((dy + o) + c4); else dv[r] = dyraw();
+      pv[r] = (ACC && ok) ? *reinterpret_cast<const float4*>((dx + o) + c4) : zero4;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float4 d = io<TDY>::cvt4(dv[r]);
+      xv[r] = make_float4((xv[r].x - mu[r]) * rs[r], (xv[r].y - mu[r]) * rs[r], (xv[r].z - mu[r]) * rs[r], (xv[r].w - mu[r]) * rs[r]);
+      const float4 g = make_float4(d.x * w4.x, d.y * w4.y, d.z * w4.z, d.w * w4.w);
+      float s1 = (g.x + g.y) + (g.z + g.w);
+      float s2 = (g.x * xv[r].x + g.y * xv[r].y) + (g.z * xv[r].z + g.w * xv[r].w);
+      s1 = wave_sum(s1);
+      s2 = wave_sum(s2);
+      if (lane == 0) {
+        red[par][r][0][wv] = s1;
+        red[par][r][1][wv] = s2;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = rbase + r;
+      float s1 = 0.f, s2 = 0.f;
+      for (int k = 0; k < nw; ++k) {
+        s1 += red[par][r][0][k];
+        s2 += red[par][r][1][k];
+      }
+      s1 *= inv_d;
+      s2 *= inv_d;
+      const float4 d = io<TDY>::cvt4(dv[r]);
+      const float4 xh = xv[r];
+      adw.x += d.x * xh.x; adw.y += d.y * xh.y; adw.z += d.z * xh.z; adw.w += d.w * xh.w;
+      adb.x += d.x; adb.y += d.y; adb.z += d.z; adb.w += d.w;
+      if (row < M && colok) {
+        float4 o;
+        o.x = pv[r].x + rs[r] * (d.x * w4.x - s1 - xh.x * s2);
+        o.y = pv[r].y + rs[r] * (d.y * w4.y - s1 - xh.y * s2);
+        o.z = pv[r].z + rs[r] * (d.z * w4.z - s1 - xh.z * s2);
+        o.w = pv[r].w + rs[r] * (d.w * w4.w - s1 - xh.w * s2);
+        const int64_t oo = (int64_t)row * D;
+        *reinterpret_cast<float4*>((dx + oo) + c4) = o;
+        if (dx_lp) io<bf16_t>::st4((dx_lp + oo) + c4, o);      // bf16 copy = A operand of the next backward GEMM
+      }
+    }
+  }
+  if (!colok) return;
+  if (part) {            // two-stage: per-workgroup partial rows, summed by ln_bwd_reduce_kernel
+    float* pr = part + (int64_t)blockIdx.x * 2 * D;
+    *reinterpret_cast<float4*>(pr + c4) = adw;
+    *reinterpret_cast<float4*>(pr + D + c4) = adb;
+    return;
+  }
+  if (dw) { atomicAdd(&dw[c4], adw.x); atomicAdd(&dw[c4 + 1], adw.y); atomicAdd(&dw[c4 + 2], adw.z); atomicAdd(&dw[c4 + 3], adw.w); }
+  if (db) { atomicAdd(&db[c4], adb.x); atomicAdd(&db[c4 + 1], adb.y); atomicAdd(&db[c4 + 2], adb.z); atomicAdd(&db[c4 + 3], adb.w); }
+}
+
+// Backward, row-owner form (any D up to 2048): one wave per row for dx; dw/db accumulated per block in LDS then atomically
+// added into fp32 dw/db (D floats each; D*gridDim atomics spread over D addresses).
 // NV = float4 per lane (compile time: D = 768 -> 3), so that only the registers a row needs are allocated and 8 waves per
 // SIMD hide the HBM latency of this pure streaming kernel.
-template <typename TDY, int NV>
+template <typename TDY, int NV, bool FULL, bool ACC>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ w, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dx,
-                                                            int accumulate_dx, bf16_t* __restrict__ dx_lp, float* __restrict__ dw,
+                                                            bf16_t* __restrict__ dx_lp, float* __restrict__ dw,
                                                             float* __restrict__ db, float* __restrict__ part, int M, int D,
                                                             int rows_per_block) {
+  // FULL: D == NV*256, every lane owns NV float4 of the row and the loads below carry no bounds branches -- with a
+  // branch per float4 the compiler waits for each chunk's loads before issuing the next chunk's (3 latencies per row).
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [2][D]
   float* s_dw = sm;
   float* s_db = sm + D;
@@ -76,49 +171,69 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TDY* __restric
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nv = D >> 2;
   const int r0 = blockIdx.x * rows_per_block;
-  float4 adw[NV], adb[NV];
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 adw[NV], adb[NV], w4[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) adw[i] = adb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < NV; ++i) {
+    adw[i] = adb[i] = zero4;
+    const int c = lane + i * 64;
+    w4[i] = (FULL || c < nv) ? *reinterpret_cast<const float4*>(w + c * 4) : zero4;
+  }
 
-  for (int rr = wv; rr < rows_per_block; rr += 4) {
-    const int row = r0 + rr;
-    if (row >= M) break;
-    const float mu = mean[row], rs = rstd[row];
-    const float* xr = x + (int64_t)row * D;
-    const TDY* dyr = dy + (int64_t)row * D;
-    float4 xh[NV], g[NV];
+  // One row ahead: the next row's loads are issued before this row's arithmetic and stores, so a wave always has a row
+  // of loads in flight and never waits for its own stores to be acknowledged before it can see new data (loads and
+  // stores share the in-order vmcnt counter on gfx9).
+  typedef typename io<TDY>::raw4 dyraw;
+  float4 nx[NV], np[NV];
+  dyraw nd[NV];
+  float nmu = 0.f, nrs = 0.f;
+  auto fetch = [&](int row) {
+    nmu = mean[row];
+    nrs = rstd[row];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + i * 64;
+      const bool in = FULL || c < nv;
+      const int64_t o = (int64_t)row * D + c * 4;
+      nx[i] = in ? *reinterpret_cast<const float4*>(x + o) : zero4;
+      if (in) nd[i] = io<TDY>::ld4_raw(dy + o); else nd[i] = dyraw();
+      np[i] = (ACC && in) ? *reinterpret_cast<const float4*>(dx + o) : zero4;
+    }
+  };
+  const int rend = min(M, r0 + rows_per_block);
+  if (r0 + wv < rend) fetch(r0 + wv);
+  for (int row = r0 + wv; row < rend; row += 4) {
+    const float mu = nmu, rs = nrs;
+    float* dxr = dx + (int64_t)row * D;
+    float4 xh[NV], g[NV], prev[NV], d[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      xh[i] = nx[i];
+      d[i] = io<TDY>::cvt4(nd[i]);
+      prev[i] = np[i];
+    }
+    if (row + 4 < rend) fetch(row + 4);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = lane + i * 64;
-      if (c < nv) {
-        const float4 xv = *reinterpret_cast<const float4*>(xr + c * 4);
-        const float4 d = io<TDY>::ld4(dyr + c * 4);
-        const float4 wv4 = *reinterpret_cast<const float4*>(w + c * 4);
-        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-        g[i] = make_float4(d.x * wv4.x, d.y * wv4.y, d.z * wv4.z, d.w * wv4.w);
-        s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
-        s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
-        adw[i].x += d.x * xh[i].x; adw[i].y += d.y * xh[i].y; adw[i].z += d.z * xh[i].z; adw[i].w += d.w * xh[i].w;
-        adb[i].x += d.x; adb[i].y += d.y; adb[i].z += d.z; adb[i].w += d.w;
-      }
+      xh[i] = make_float4((xh[i].x - mu) * rs, (xh[i].y - mu) * rs, (xh[i].z - mu) * rs, (xh[i].w - mu) * rs);
+      g[i] = make_float4(d[i].x * w4[i].x, d[i].y * w4[i].y, d[i].z * w4[i].z, d[i].w * w4[i].w);
+      s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+      s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+      adw[i].x += d[i].x * xh[i].x; adw[i].y += d[i].y * xh[i].y; adw[i].z += d[i].z * xh[i].z; adw[i].w += d[i].w * xh[i].w;
+      adb[i].x += d[i].x; adb[i].y += d[i].y; adb[i].z += d[i].z; adb[i].w += d[i].w;
     }
     s1 = wave_sum(s1) / (float)D;
     s2 = wave_sum(s2) / (float)D;
-    float* dxr = dx + (int64_t)row * D;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = lane + i * 64;
-      if (c < nv) {
+      if (FULL || c < nv) {
         float4 o;
-        o.x = rs * (g[i].x - s1 - xh[i].x * s2);
-        o.y = rs * (g[i].y - s1 - xh[i].y * s2);
-        o.z = rs * (g[i].z - s1 - xh[i].z * s2);
-        o.w = rs * (g[i].w - s1 - xh[i].w * s2);
-        if (accumulate_dx) {
-          const float4 p = *reinterpret_cast<const float4*>(dxr + c * 4);
-          o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
-        }
+        o.x = prev[i].x + rs * (g[i].x - s1 - xh[i].x * s2);
+        o.y = prev[i].y + rs * (g[i].y - s1 - xh[i].y * s2);
+        o.z = prev[i].z + rs * (g[i].z - s1 - xh[i].z * s2);
+        o.w = prev[i].w + rs * (g[i].w - s1 - xh[i].w * s2);
         *reinterpret_cast<float4*>(dxr + c * 4) = o;
         if (dx_lp) io<bf16_t>::st4(dx_lp + (int64_t)row * D + c * 4, o);   // bf16 copy = A operand of the next backward GEMM
       }
@@ -214,6 +329,77 @@ __global__ __launch_bounds__(256) void batchnorm_fwd_kernel(const float* __restr
   }
 }
 
+// Sliced form for Bn <= 128: 64 features x 4 row slices per workgroup, the slice's rows live in registers (one memory
+// latency for the whole column instead of three serial passes of Bn dependent loads), sums cross the waves through LDS.
+template <typename TY>
+__global__ __launch_bounds__(256) void batchnorm_fwd_sliced_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                   const float* __restrict__ b, float* __restrict__ rmean,
+                                                                   float* __restrict__ rvar, int training, float momentum, float eps,
+                                                                   TY* __restrict__ y, float* __restrict__ save_mean,
+                                                                   float* __restrict__ save_invstd, int Bn, int F, int gsz,
+                                                                   int n_inner, int n_outer, int64_t pstride, int64_t sstride,
+                                                                   const float* __restrict__ gate) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + lane;
+  const bool fok = f < F;
+  const int fc = fok ? f : F - 1;
+  int64_t pi = fc, si = fc;
+  int gi = 0, go = 0;
+  if (gsz > 0) {
+    const int g = fc / gsz, k = fc - g * gsz;
+    gi = g % n_inner; go = g / n_inner;
+    const int64_t blk = (int64_t)gi * n_outer + go;
+    pi = blk * pstride + k;
+    si = blk * sstride + k;
+  }
+  float xr[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int r = wv + 4 * i;
+    xr[i] = (fok && r < Bn) ? x[(int64_t)r * F + f] : 0.f;
+  }
+  float mean, invstd;
+  if (training) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += xr[i];
+    red[wv][lane] = s;
+    __syncthreads();
+    mean = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) / (float)Bn;
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const float dlt = xr[i] - mean;
+      if (wv + 4 * i < Bn) q += dlt * dlt;
+    }
+    red[wv][lane] = q;
+    __syncthreads();
+    const float var = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) / (float)Bn;
+    invstd = rsqrtf(var + eps);
+    if (wv == 0 && fok) {
+      rmean[si] = (1.f - momentum) * rmean[si] + momentum * mean;
+      rvar[si] = (1.f - momentum) * rvar[si] + momentum * (var * (float)Bn / (float)(Bn - 1));
+      if (save_mean) save_mean[f] = mean;
+      if (save_invstd) save_invstd[f] = invstd;
+    }
+  } else {
+    mean = rmean[si];
+    invstd = rsqrtf(rvar[si] + eps);
+  }
+  const float sc = invstd * w[pi], sh = b[pi] - mean * sc;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int r = wv + 4 * i;
+    if (fok && r < Bn) {
+      float v = xr[i] * sc + sh;
+      if (gate) v *= gate[((int64_t)r * n_inner + gi) * n_outer + go];
+      io<TY>::st(y + (int64_t)r * F + f, v);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int demo_layernorm_fwd(const float* x, const float* w, const float* b, float eps, void* y, int32_t dtY,
@@ -242,15 +428,39 @@ extern "C" int demo_layernorm_bwd(const void* dy, int32_t dtDy, const float* x, 
   // thousands of workgroups atomically adding into the same 2*D words serialise; with a workspace each workgroup stores
   // its partial dw/db row and a second tiny kernel sums the rows
   float* part = (workspace && workspace_elems >= (int64_t)nblk * 2 * D && (dw || db)) ? workspace : nullptr;
+  if (D <= 1024) {
+    const dim3 blk((unsigned)(cdiv64(D, 256) * 64));
+#define LN_BWD_COLS(T_, ACC_)                                                                                                   \
+  hipLaunchKernelGGL((layernorm_bwd_cols_kernel<T_, 4, ACC_>), grid, blk, 0, s, (const T_*)dy, x, w, mean, rstd, dx,            \
+                     (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block)
+    if (dtDy == DEMO_BF16) { if (accumulate_dx) LN_BWD_COLS(bf16_t, true); else LN_BWD_COLS(bf16_t, false); }
+    else { if (accumulate_dx) LN_BWD_COLS(float, true); else LN_BWD_COLS(float, false); }
+#undef LN_BWD_COLS
+    DEMO_LAUNCH_CHECK("demo_layernorm_bwd");
+    if (part) {
+      hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv64(2 * D, 256), (unsigned)(nblk >= 64 ? 32 : 1)), dim3(256), 0, s,
+                         part, nblk, D, dw, db);
+      DEMO_LAUNCH_CHECK("demo_layernorm_bwd(reduce)");
+    }
+    return 0;
+  }
   const int nvl = (int)cdiv64(D, 256);      // float4 per lane actually needed
-#define LN_BWD_LAUNCH(NV_)                                                                                                      \
+#define LN_BWD_LAUNCH2(NV_, FULL_, ACC_)                                                                                        \
   do {                                                                                                                          \
     if (dtDy == DEMO_BF16)                                                                                                      \
-      hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, NV_>), grid, dim3(256), shm, s, (const bf16_t*)dy, x, w, mean, rstd, dx, \
-                         accumulate_dx, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block);                                  \
+      hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, NV_, FULL_, ACC_>), grid, dim3(256), shm, s, (const bf16_t*)dy, x, w,    \
+                         mean, rstd, dx, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block);                                 \
     else                                                                                                                        \
-      hipLaunchKernelGGL((layernorm_bwd_kernel<float, NV_>), grid, dim3(256), shm, s, (const float*)dy, x, w, mean, rstd, dx,   \
-                         accumulate_dx, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block);                                  \
+      hipLaunchKernelGGL((layernorm_bwd_kernel<float, NV_, FULL_, ACC_>), grid, dim3(256), shm, s, (const float*)dy, x, w,      \
+                         mean, rstd, dx, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block);                                 \
+  } while (0)
+#define LN_BWD_LAUNCH(NV_)                                                                                                      \
+  do {                                                                                                                          \
+    const bool full = D == NV_ * 256;                                                                                           \
+    if (full && accumulate_dx) LN_BWD_LAUNCH2(NV_, true, true);                                                                 \
+    else if (full) LN_BWD_LAUNCH2(NV_, true, false);                                                                            \
+    else if (accumulate_dx) LN_BWD_LAUNCH2(NV_, false, true);                                                                   \
+    else LN_BWD_LAUNCH2(NV_, false, false);                                                                                     \
   } while (0)
   if (nvl <= 1) LN_BWD_LAUNCH(1);
   else if (nvl <= 2) LN_BWD_LAUNCH(2);
@@ -258,6 +468,7 @@ extern "C" int demo_layernorm_bwd(const void* dy, int32_t dtDy, const float* x, 
   else if (nvl <= 4) LN_BWD_LAUNCH(4);
   else if (nvl <= 6) LN_BWD_LAUNCH(6);
   else LN_BWD_LAUNCH(8);
+#undef LN_BWD_LAUNCH2
 #undef LN_BWD_LAUNCH
   DEMO_LAUNCH_CHECK("demo_layernorm_bwd");
   if (part) {
@@ -268,7 +479,7 @@ extern "C" int demo_layernorm_bwd(const void* dy, int32_t dtDy, const float* x, 
   return 0;
 }
 
-extern "C" int64_t demo_layernorm_bwd_workspace(int32_t M, int32_t D) { return cdiv64(M, 16) * 2 * (int64_t)D; }
+extern "C" int64_t demo_layernorm_bwd_workspace(int32_t M, int32_t D) { return cdiv64(M, 8) * 2 * (int64_t)D; }
 
 extern "C" int demo_batchnorm_fwd(const float* x, const float* w, const float* b, float* running_mean, float* running_var,
                                   int32_t training, float momentum, float eps, void* y, int32_t dtY, float* save_mean,
@@ -279,6 +490,16 @@ extern "C" int demo_batchnorm_fwd(const float* x, const float* w, const float* b
   DEMO_REQUIRE(!gate || gsz > 0, "demo_batchnorm_fwd: gate requires grouping");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)cdiv64(F, 64));
+  if (Bn <= 128) {
+    if (dtY == DEMO_BF16)
+      hipLaunchKernelGGL(batchnorm_fwd_sliced_kernel<bf16_t>, grid, dim3(256), 0, s, x, w, b, running_mean, running_var, training,
+                         momentum, eps, (bf16_t*)y, save_mean, save_invstd, Bn, F, gsz, n_inner, n_outer, pstride, sstride, gate);
+    else
+      hipLaunchKernelGGL(batchnorm_fwd_sliced_kernel<float>, grid, dim3(256), 0, s, x, w, b, running_mean, running_var, training,
+                         momentum, eps, (float*)y, save_mean, save_invstd, Bn, F, gsz, n_inner, n_outer, pstride, sstride, gate);
+    DEMO_LAUNCH_CHECK("demo_batchnorm_fwd");
+    return 0;
+  }
   if (dtY == DEMO_BF16)
     hipLaunchKernelGGL(batchnorm_fwd_kernel<bf16_t>, grid, dim3(64), 0, s, x, w, b, running_mean, running_var, training,
                        momentum, eps, (bf16_t*)y, save_mean, save_invstd, Bn, F, gsz, n_inner, n_outer, pstride, sstride, gate);

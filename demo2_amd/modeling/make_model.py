@@ -294,10 +294,23 @@ class DeMo(_Holder):
             dst = P.extra.get((g.k_proj, T))
             P.extra[(g.k_proj, T)] = ops.transpose(P.w(g.k_proj, T), dst)
         if self.training and T == torch.bfloat16:
-            for i in range(g.layers):
-                k = g.block_keys(i)
-                for name in (k["qkv_w"], k["proj_w"], k["fc1_w"], k["fc2_w"]):
-                    P.extra[("t", name)] = ops.transpose(P.w(name, T), P.extra.get(("t", name)))
+            keys = [g.block_keys(i) for i in range(g.layers)]
+            for kind in ("qkv_w", "proj_w", "fc1_w", "fc2_w"):
+                names = [k[kind] for k in keys]
+                rows, cols = P.index[names[0]][1]
+                offs = [P.off(n) for n in names]
+                steps = {b - a for a, b in zip(offs, offs[1:])}
+                if len(steps) <= 1:
+                    # the layers' weights of one kind sit at a constant stride in the flat buffer: one batched launch
+                    buf = P.extra.get(("tb", kind))
+                    if buf is None:
+                        buf = P.extra[("tb", kind)] = torch.empty(len(names), cols, rows, device=P.shadow.device, dtype=T)
+                    ops.transpose_batched(P.shadow, offs[0], steps.pop() if steps else 0, rows, cols, len(names), buf)
+                    for i, name in enumerate(names):
+                        P.extra[("t", name)] = buf[i]
+                else:
+                    for name in names:
+                        P.extra[("t", name)] = ops.transpose(P.w(name, T), P.extra.get(("t", name)))
 
     def anchor(self) -> torch.Tensor:
         """1-element leaf that ties the kernel schedule into autograd (its own gradient is never produced)."""

@@ -142,6 +142,17 @@ def transpose(src: Tensor, dst: Optional[Tensor] = None) -> Tensor:
     return dst
 
 
+def transpose_batched(src_flat: Tensor, src_off: int, src_stride: int, rows: int, cols: int, batch: int, dst: Tensor) -> Tensor:
+    """dst[z] (cols, rows) = src_flat[src_off + z*src_stride :][:rows*cols].view(rows, cols)^T for z < batch, one launch."""
+    _req_cuda(src_flat, dst)
+    assert dst.is_contiguous() and dst.shape == (batch, cols, rows) and dst.dtype == src_flat.dtype
+    assert src_off + (batch - 1) * src_stride + rows * cols <= src_flat.numel()
+    esz = src_flat.element_size()
+    check(_lib.load().demo_transpose_batched(src_flat.data_ptr() + src_off * esz, dst.data_ptr(), rows, cols, batch, src_stride,
+                                             rows * cols, dt_code(src_flat.dtype), _stream()), "demo_transpose_batched")
+    return dst
+
+
 def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
     _req_cuda(x)
     assert x.dim() == 2 and x.stride(1) == 1

@@ -74,6 +74,10 @@ int demo_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 int demo_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream);
 /* 2-D transpose with dtype preserved: dst[c, r] = src[r, c]; used for weight^T shadows (backward). */
 int demo_transpose(const void* src, void* dst, int32_t rows, int32_t cols, int32_t dt, void* stream);
+/* the same for `batch` equally shaped matrices src + z*src_stride -> dst + z*dst_stride (strides in elements): one launch for
+   the W^T shadows of all layers' Linear weights of one kind, which sit at a constant stride in the flat parameter buffer. */
+int demo_transpose_batched(const void* src, void* dst, int32_t rows, int32_t cols, int32_t batch, int64_t src_stride,
+                           int64_t dst_stride, int32_t dt, void* stream);
 /* column sums: out[n] (+)= sum_m X[m, n]   (bias gradients) */
 int demo_colsum(const void* X, float* out, int32_t M, int32_t N, int64_t ldx, int32_t dt, int32_t accumulate, void* stream);
 
