@@ -5,16 +5,21 @@
 //     S = Q K^T * scale,  P = exp(S - LSE),  dV = P^T dO,  dP = dO V^T,  delta = rowsum(dO * O),
 //     dS = P * (dP - delta) * scale,  dQ = dS K,  dK = dS^T Q.
 //
-// bf16 kernel: one 256-thread workgroup per (image, head); Q, K, V, dO zero-padded to 160 rows in LDS (128-B rows,
+// bf16 kernel: one 256-thread workgroup per (image, head); Q, dO, K, V zero-padded to NT*16 rows in LDS (128-B rows,
 // 16-B chunk index ^= row&6: conflict free for ds_read_b128 row reads AND for the transposing reads below).
-// Orientation follows the CDNA4 "key on the lane" recipe: S and dP tiles are computed as
-// mfma(A = Q / dO rows, B = K / V rows), so an accumulator holds 4 QUERIES (registers) x 1 KEY (lane); converted to
-// bf16, two such tiles are directly the B operand of
-//     dV^T += dO^T P,   dK^T += Q^T dS        (sum over queries; A = ds_read_b64_tr_b16 of dO / Q)
-// with no cross-lane movement.  Each wave owns key tiles, so dK/dV need no cross-wave sum.  dS^T is written once
-// to LDS ([key][query], 8 B per lane) and, after one barrier, each wave forms dQ^T = K^T dS^T for its query tiles
-// (A = transposing read of K, B = transposing read of dS^T).  The k index inside every 32-deep MFMA step is
-// permuted identically on both operands ({4g+j, 16+4g+j}), which the sum does not see.
+// Orientation follows the CDNA4 "key on the lane" recipe.
+//   pass A (a wave owns KEY tiles, walks all queries):  S and dP tiles are mfma(A = Q / dO rows, B = K / V rows), so an
+//     accumulator holds 4 QUERIES (registers) x 1 KEY (lane); converted to bf16, two such tiles are directly the B operand of
+//         dV^T += dO^T P,   dK^T += Q^T dS        (sum over queries; A = ds_read_b64_tr_b16 of dO / Q)
+//     with no cross-lane movement and no cross-wave sum.
+//   pass B (a wave owns QUERY tiles, walks all keys):   the mirrored form, S^T / dP^T = mfma(A = K / V rows, B = Q / dO rows)
+//     = 4 KEYS (registers) x 1 QUERY (lane), recomputed rather than exchanged: its bf16 image is the B operand of
+//         dQ^T += K^T dS^T                         (sum over keys; A = transposing read of K).
+//     Recomputing S and dP costs 8 MFMAs per 32 keys; the alternative (dS^T through LDS) costs 56 KB of LDS and a
+//     barrier, and it is LDS capacity that decides whether TWO workgroups fit a CU: with NT = 9 (L <= 144, the 129-token
+//     ViT sequence) the footprint is 73 KB, so one workgroup's global-load phase hides under the other's MFMA phase.
+// The k index inside every 32-deep MFMA step is permuted identically on both operands ({4g+j, 16+4g+j}), which the sum
+// does not see.  Tiles past NT (odd NT: second half of the last pair) are masked to zero contributions.
 //
 // generic kernel: fp32 math on the vector ALUs (parity mode and shapes outside the MFMA kernel's contract).
 #include "common.h"
@@ -24,11 +29,7 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
-constexpr int LP = 160;                       // padded rows (10 tiles of 16)
-constexpr int MAT_BYTES = LP * 128;           // 20 KiB per 160 x 64 bf16 matrix
-constexpr int DST_STRIDE = 352;               // bytes per dS^T row (160 queries * 2 B + 32 B pad: conflict-free tr reads)
-constexpr int DST_BYTES = LP * DST_STRIDE;
-constexpr int SMEM_BYTES = 4 * MAT_BYTES + DST_BYTES + 2 * LP * 4;
+constexpr int LP_MAX = 160;                   // 10 tiles of 16 rows
 
 __device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ (r & 6)) << 4); }
 
@@ -37,17 +38,27 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base, int off_lo, int off_
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + off_hi));
   return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
+// second half only when that tile exists (wave-uniform), else zeros
+__device__ __forceinline__ bf16x8 tr_frag_opt(const char* base, int off_lo, int off_hi, bool hi_ok) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + off_lo));
+  s16x4 hi = {0, 0, 0, 0};
+  if (hi_ok) hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + off_hi));
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
 
-__global__ __launch_bounds__(256, 1) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
-                                                               const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                               bf16_t* __restrict__ dqkv, int L, int H, float scale) {
-  __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];
+template <int NT>
+__global__ __launch_bounds__(256, NT <= 9 ? 2 : 1) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv,
+                                                                             const bf16_t* __restrict__ out,
+                                                                             const bf16_t* __restrict__ dout,
+                                                                             const float* __restrict__ lse,
+                                                                             bf16_t* __restrict__ dqkv, int L, int H, float scale) {
+  constexpr int LP = NT * 16, MAT_BYTES = LP * 128, NPAIR = (NT + 1) / 2, NIT = (LP * 8 + 255) / 256;
+  __shared__ __attribute__((aligned(1024))) char smem[4 * MAT_BYTES + 2 * LP * 4];
   char* Qs = smem;
-  char* Ks = smem + MAT_BYTES;
-  char* Vs = smem + 2 * MAT_BYTES;
-  char* Gs = smem + 3 * MAT_BYTES;            // dO
-  char* DSt = smem + 4 * MAT_BYTES;           // dS^T [key][query]
-  float* lse2 = reinterpret_cast<float*>(smem + 4 * MAT_BYTES + DST_BYTES);   // LSE * log2(e)
+  char* Gs = smem + MAT_BYTES;                // dO
+  char* Ks = smem + 2 * MAT_BYTES;
+  char* Vs = smem + 3 * MAT_BYTES;
+  float* lse2 = reinterpret_cast<float*>(smem + 4 * MAT_BYTES);   // LSE * log2(e)
   float* dlt = lse2 + LP;                     // delta
 
   const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
@@ -60,9 +71,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_bf16_kernel(const bf16_t* __r
 
   // ---- stage Q, K, V, dO (all loads issued before the LDS writes), delta = rowsum(dO * O) ------------------
   {
-    uint4 vq[5], vk[5], vv[5], vg[5], vo[5];
+    uint4 vq[NIT], vk[NIT], vv[NIT], vg[NIT], vo[NIT];
 #pragma unroll
-    for (int it = 0; it < 5; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int idx = tid + it * 256, r = idx >> 3, c = idx & 7;
       const uint4 z = make_uint4(0u, 0u, 0u, 0u);
       vq[it] = vk[it] = vv[it] = vg[it] = vo[it] = z;
@@ -76,13 +87,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_bf16_kernel(const bf16_t* __r
       }
     }
 #pragma unroll
-    for (int it = 0; it < 5; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int idx = tid + it * 256, r = idx >> 3, c = idx & 7;
-      const int o = swz(r, c);
-      *reinterpret_cast<uint4*>(Qs + o) = vq[it];
-      *reinterpret_cast<uint4*>(Ks + o) = vk[it];
-      *reinterpret_cast<uint4*>(Vs + o) = vv[it];
-      *reinterpret_cast<uint4*>(Gs + o) = vg[it];
       const uint32_t gw[4] = {vg[it].x, vg[it].y, vg[it].z, vg[it].w};
       const uint32_t ow[4] = {vo[it].x, vo[it].y, vo[it].z, vo[it].w};
       float d = 0.f;
@@ -94,7 +100,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_bf16_kernel(const bf16_t* __r
       d += __shfl_xor(d, 1, 64);
       d += __shfl_xor(d, 2, 64);
       d += __shfl_xor(d, 4, 64);
-      if (c == 0) dlt[r] = d;
+      if (r < LP) {
+        const int o = swz(r, c);
+        *reinterpret_cast<uint4*>(Qs + o) = vq[it];
+        *reinterpret_cast<uint4*>(Ks + o) = vk[it];
+        *reinterpret_cast<uint4*>(Vs + o) = vv[it];
+        *reinterpret_cast<uint4*>(Gs + o) = vg[it];
+        if (c == 0) dlt[r] = d;
+      }
     }
     if (tid < LP) lse2[tid] = tid < L ? lse[((int64_t)b * H + h) * L + tid] * 1.4426950408889634f : 0.f;
   }
@@ -110,126 +123,155 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_bf16_kernel(const bf16_t* __r
   int to[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) to[dt] = swz(trow, dt * 2 + (tp >> 1)) + ((tp & 1) << 3);
-  // dS^T image: row = key, 2 B per query; transposing read of block rows (keys) x 16 queries
-  const int dst_tr = trow * DST_STRIDE + tp * 8;        // + key_block*DST_STRIDE*? handled by caller, + query tile * 32 B
   const float c2 = scale * 1.4426950408889634f;
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-  // ================= phase A: this wave's key tiles; all query pairs =========================================
-  // key tiles per wave: 10 tiles -> waves 0,1 take 3 (kt = w, w+4, w+8), waves 2,3 take 2
-  const int nkt = wave < 2 ? 3 : 2;
-  f32x4 dVa[3][4], dKa[3][4];
+  // ================= pass A: this wave's key tiles (kt = wave, wave+4, wave+8 < NT); all query pairs ==============
+  {
+    f32x4 dVa[3][4], dKa[3][4];
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { dVa[a][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dKa[a][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      for (int dt = 0; dt < 4; ++dt) { dVa[a][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dKa[a][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-  for (int qp = 0; qp < 5; ++qp) {
-    // row fragments of the two query tiles (A operands of S and dP)
-    bf16x8 qf[2][2], gf[2][2];
+    for (int qp = 0; qp < NPAIR; ++qp) {
+      const bool t1 = qp * 2 + 1 < NT;                       // second query tile of the pair exists
+      // row fragments of the two query tiles (A operands of S and dP)
+      bf16x8 qf[2][2], gf[2][2];
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int rb = (qp * 2 + hh) * 2048;
-      qf[hh][0] = *reinterpret_cast<const bf16x8*>(Qs + rb + fo0);
-      qf[hh][1] = *reinterpret_cast<const bf16x8*>(Qs + rb + fo1);
-      gf[hh][0] = *reinterpret_cast<const bf16x8*>(Gs + rb + fo0);
-      gf[hh][1] = *reinterpret_cast<const bf16x8*>(Gs + rb + fo1);
-    }
-    // transposed fragments (A operands of dV^T and dK^T): k = queries {4g+j, 16+4g+j} of this pair
-    bf16x8 qt[4], gt[4];
+      for (int hh = 0; hh < 2; ++hh) {
+        const int rb = (qp * 2 + hh) * 2048;
+        if (hh == 0 || t1) {
+          qf[hh][0] = *reinterpret_cast<const bf16x8*>(Qs + rb + fo0);
+          qf[hh][1] = *reinterpret_cast<const bf16x8*>(Qs + rb + fo1);
+          gf[hh][0] = *reinterpret_cast<const bf16x8*>(Gs + rb + fo0);
+          gf[hh][1] = *reinterpret_cast<const bf16x8*>(Gs + rb + fo1);
+        } else {
+          qf[hh][0] = qf[hh][1] = gf[hh][0] = gf[hh][1] = zero8;
+        }
+      }
+      // transposed fragments (A operands of dV^T and dK^T): k = queries {4g+j, 16+4g+j} of this pair
+      bf16x8 qt[4], gt[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      qt[dt] = tr_frag(Qs + qp * 4096, to[dt], to[dt] + 2048);
-      gt[dt] = tr_frag(Gs + qp * 4096, to[dt], to[dt] + 2048);
-    }
-    // per-lane row constants: queries qbase + 4g + r for both tiles
-    float l2[2][4], dl[2][4];
+      for (int dt = 0; dt < 4; ++dt) {
+        qt[dt] = tr_frag_opt(Qs + qp * 4096, to[dt], to[dt] + 2048, t1);
+        gt[dt] = tr_frag_opt(Gs + qp * 4096, to[dt], to[dt] + 2048, t1);
+      }
+      // per-lane row constants: queries qbase + 4g + r for both tiles
+      float l2[2][4], dl[2][4];
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const float4 a = *reinterpret_cast<const float4*>(lse2 + (qp * 2 + hh) * 16 + 4 * g);
-      const float4 d = *reinterpret_cast<const float4*>(dlt + (qp * 2 + hh) * 16 + 4 * g);
-      l2[hh][0] = a.x; l2[hh][1] = a.y; l2[hh][2] = a.z; l2[hh][3] = a.w;
-      dl[hh][0] = d.x; dl[hh][1] = d.y; dl[hh][2] = d.z; dl[hh][3] = d.w;
-    }
+      for (int hh = 0; hh < 2; ++hh) {
+        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), d4 = a4;
+        if (hh == 0 || t1) {
+          a4 = *reinterpret_cast<const float4*>(lse2 + (qp * 2 + hh) * 16 + 4 * g);
+          d4 = *reinterpret_cast<const float4*>(dlt + (qp * 2 + hh) * 16 + 4 * g);
+        }
+        l2[hh][0] = a4.x; l2[hh][1] = a4.y; l2[hh][2] = a4.z; l2[hh][3] = a4.w;
+        dl[hh][0] = d4.x; dl[hh][1] = d4.y; dl[hh][2] = d4.z; dl[hh][3] = d4.w;
+      }
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      if (a < nkt) {                                       // wave-uniform
+      for (int a = 0; a < 3; ++a) {
         const int kt = wave + 4 * a;
-        const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(Ks + kt * 2048 + fo0);
-        const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(Ks + kt * 2048 + fo1);
-        const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(Vs + kt * 2048 + fo0);
-        const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(Vs + kt * 2048 + fo1);
-        bf16x8 pb, db;
+        if (kt < NT) {                                       // wave-uniform
+          const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(Ks + kt * 2048 + fo0);
+          const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(Ks + kt * 2048 + fo1);
+          const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(Vs + kt * 2048 + fo0);
+          const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(Vs + kt * 2048 + fo1);
+          bf16x8 pb, db;
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[hh][0], kf0, s, 0, 0, 0);
-          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[hh][1], kf1, s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[hh][0], vf0, dp, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[hh][1], vf1, dp, 0, 0, 0);
-          bf16x4 dsv;
+          for (int hh = 0; hh < 2; ++hh) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[hh][0], kf0, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[hh][1], kf1, s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[hh][0], vf0, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[hh][1], vf1, dp, 0, 0, 0);
+            const bool tv = hh == 0 || t1;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = exp2f(s[r] * c2 - l2[hh][r]);
-            const float ds = p * (dp[r] - dl[hh][r]) * scale;
-            pb[hh * 4 + r] = (short)f2bf(p);
-            db[hh * 4 + r] = (short)f2bf(ds);
-            dsv[r] = db[hh * 4 + r];
+            for (int r = 0; r < 4; ++r) {
+              const float p = exp2f(s[r] * c2 - l2[hh][r]);
+              const float ds = p * (dp[r] - dl[hh][r]) * scale;
+              pb[hh * 4 + r] = tv ? (short)f2bf(p) : (short)0;
+              db[hh * 4 + r] = tv ? (short)f2bf(ds) : (short)0;
+            }
           }
-          // dS^T[key = kt*16 + li][query = (2qp+hh)*16 + 4g .. +3]
-          *reinterpret_cast<bf16x4*>(DSt + (kt * 16 + li) * DST_STRIDE + ((qp * 2 + hh) * 16 + 4 * g) * 2) = dsv;
-        }
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          dVa[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt[dt], pb, dVa[a][dt], 0, 0, 0);
-          dKa[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt[dt], db, dKa[a][dt], 0, 0, 0);
-        }
-      }
-    }
-  }
-  // dK^T / dV^T tiles: D[row = d = 4g + reg][col = key = li] -> 4 consecutive d per lane
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    if (a < nkt) {
-      const int key = (wave + 4 * a) * 16 + li;
-      if (key < L) {
-        bf16_t* row = dqkv + ((int64_t)b * L + key) * ld3 + h * 64 + 4 * g;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          io<bf16_t>::st4(row + D + dt * 16, make_float4(dKa[a][dt][0], dKa[a][dt][1], dKa[a][dt][2], dKa[a][dt][3]));
-          io<bf16_t>::st4(row + 2 * D + dt * 16, make_float4(dVa[a][dt][0], dVa[a][dt][1], dVa[a][dt][2], dVa[a][dt][3]));
-        }
-      }
-    }
-  }
-  __syncthreads();
-
-  // ================= phase B: dQ^T = K^T dS^T for this wave's query tiles ====================================
-  const int nqt = wave < 2 ? 3 : 2;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    if (a < nqt) {
-      const int qtile = wave + 4 * a;
-      if (qtile * 16 < L) {
-        f32x4 dq[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 5; ++ks) {
-          // B operand: dS^T rows (keys) {32ks + 4g + j, +16}, column = query li of tile qtile
-          const bf16x8 sb = tr_frag(DSt + ks * 32 * DST_STRIDE + qtile * 32, dst_tr, dst_tr + 16 * DST_STRIDE);
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) {
-            const bf16x8 ka = tr_frag(Ks + ks * 4096, to[dt], to[dt] + 2048);
-            dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, sb, dq[dt], 0, 0, 0);
+            dVa[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt[dt], pb, dVa[a][dt], 0, 0, 0);
+            dKa[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt[dt], db, dKa[a][dt], 0, 0, 0);
           }
         }
-        const int q = qtile * 16 + li;
-        if (q < L) {
-          bf16_t* row = dqkv + ((int64_t)b * L + q) * ld3 + h * 64 + 4 * g;
+      }
+    }
+    // dK^T / dV^T tiles: D[row = d = 4g + reg][col = key = li] -> 4 consecutive d per lane
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt)
-            io<bf16_t>::st4(row + dt * 16, make_float4(dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]));
+    for (int a = 0; a < 3; ++a) {
+      const int kt = wave + 4 * a;
+      if (kt < NT) {
+        const int key = kt * 16 + li;
+        if (key < L) {
+          bf16_t* row = dqkv + ((int64_t)b * L + key) * ld3 + h * 64 + 4 * g;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            io<bf16_t>::st4(row + D + dt * 16, make_float4(dKa[a][dt][0], dKa[a][dt][1], dKa[a][dt][2], dKa[a][dt][3]));
+            io<bf16_t>::st4(row + 2 * D + dt * 16, make_float4(dVa[a][dt][0], dVa[a][dt][1], dVa[a][dt][2], dVa[a][dt][3]));
+          }
         }
+      }
+    }
+  }
+
+  // ================= pass B: this wave's query tiles (wave, wave+4, wave+8 < NT); all key pairs =====================
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int qtile = wave + 4 * a;
+    if (qtile < NT && qtile * 16 < L) {                      // wave-uniform
+      const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(Qs + qtile * 2048 + fo0);
+      const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(Qs + qtile * 2048 + fo1);
+      const bf16x8 gf0 = *reinterpret_cast<const bf16x8*>(Gs + qtile * 2048 + fo0);
+      const bf16x8 gf1 = *reinterpret_cast<const bf16x8*>(Gs + qtile * 2048 + fo1);
+      const float l2q = lse2[qtile * 16 + li], dlq = dlt[qtile * 16 + li];      // this lane's query
+      f32x4 dq[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int kp = 0; kp < NPAIR; ++kp) {
+        const bool t1 = kp * 2 + 1 < NT;
+        bf16x8 dsb;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const bool tv = hh == 0 || t1;
+          const int kb = (kp * 2 + hh) * 2048;
+          bf16x8 kf0 = zero8, kf1 = zero8, vf0 = zero8, vf1 = zero8;
+          if (tv) {
+            kf0 = *reinterpret_cast<const bf16x8*>(Ks + kb + fo0);
+            kf1 = *reinterpret_cast<const bf16x8*>(Ks + kb + fo1);
+            vf0 = *reinterpret_cast<const bf16x8*>(Vs + kb + fo0);
+            vf1 = *reinterpret_cast<const bf16x8*>(Vs + kb + fo1);
+          }
+          // D[row = key 4g + reg][col = query li]
+          f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf0, s, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf1, s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, gf0, dp, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, gf1, dp, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = exp2f(s[r] * c2 - l2q);
+            const float ds = p * (dp[r] - dlq) * scale;
+            dsb[hh * 4 + r] = tv ? (short)f2bf(ds) : (short)0;
+          }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16x8 ka = tr_frag_opt(Ks + kp * 4096, to[dt], to[dt] + 2048, t1);
+          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, dsb, dq[dt], 0, 0, 0);
+        }
+      }
+      const int q = qtile * 16 + li;
+      if (q < L) {
+        bf16_t* row = dqkv + ((int64_t)b * L + q) * ld3 + h * 64 + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          io<bf16_t>::st4(row + dt * 16, make_float4(dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]));
       }
     }
   }
@@ -311,9 +353,13 @@ extern "C" int demo_attention_bwd(const void* qkv, const void* out, const void* 
   hipStream_t s = (hipStream_t)stream;
   const float scale = 0.125f;
   auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  if (dt == DEMO_BF16 && L <= LP && al(qkv) && al(out) && al(dout) && al(dqkv)) {
-    hipLaunchKernelGGL(attn_bwd_bf16_kernel, dim3(Bn * H), dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)out,
-                       (const bf16_t*)dout, lse, (bf16_t*)dqkv, L, H, scale);
+  if (dt == DEMO_BF16 && L <= LP_MAX && al(qkv) && al(out) && al(dout) && al(dqkv)) {
+    if (L <= 144)       // 9 row tiles: 73 KB of LDS, two workgroups per CU
+      hipLaunchKernelGGL(attn_bwd_bf16_kernel<9>, dim3(Bn * H), dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)out,
+                         (const bf16_t*)dout, lse, (bf16_t*)dqkv, L, H, scale);
+    else
+      hipLaunchKernelGGL(attn_bwd_bf16_kernel<10>, dim3(Bn * H), dim3(256), 0, s, (const bf16_t*)qkv, (const bf16_t*)out,
+                         (const bf16_t*)dout, lse, (bf16_t*)dqkv, L, H, scale);
   } else {
     const size_t shm = sizeof(float) * (2 * (size_t)L * 65 + 2 * (size_t)L * 64 + 4 * (128 + 2 * (size_t)L));
     DEMO_REQUIRE(shm <= 160 * 1024, "demo_attention_bwd: L=%d needs %zu B of LDS", L, shm);

@@ -79,11 +79,10 @@ __device__ __forceinline__ void write_tile_regs(const uint4 (&r)[ROWS / 8 / NW],
 }
 
 // bias -> (save pre-activation) -> activation -> * act'(pre) -> + residual -> (+= C) -> store, for 4 consecutive columns
-__device__ __forceinline__ void epi4(const FArgs& p, const float* __restrict__ bias, int64_t coff, int m, int n, float (&v)[4]) {
-  if (bias) {
-    const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
-    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-  }
+// (the bias quad is passed by value: in the LDS-staged epilogues a thread owns the same 8 columns for every row it stores, so
+// the caller loads it once per output tile instead of once per row, a dependent L2 round trip each time)
+__device__ __forceinline__ void epi4(const FArgs& p, const float4 b4, int64_t coff, int m, int n, float (&v)[4]) {
+  v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
   const int64_t ci = coff + (int64_t)m * p.ldc + n;
   if (p.pre_out) {
     if (p.dtC == DEMO_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.pre_out) + ci) = make_float4(v[0], v[1], v[2], v[3]);
@@ -309,17 +308,23 @@ void gemm_bf16_nt_kernel(const FArgs p) {
     }
     __syncthreads();
     constexpr int CPR = BN / 8;                           // 8-float chunks per row
+    static_assert((NW * 64) % CPR == 0, "a thread must own the same column chunk in every pass");
+    const int c = threadIdx.x % CPR;
+    float4 bz0 = make_float4(0.f, 0.f, 0.f, 0.f), bz1 = bz0;
+    if (bias) {
+      bz0 = *reinterpret_cast<const float4*>(bias + n0 + c * 8);
+      bz1 = *reinterpret_cast<const float4*>(bias + n0 + c * 8 + 4);
+    }
 #pragma unroll 4
     for (int it = 0; it < (BM * CPR) / (NW * 64); ++it) {
-      const int idx = it * (NW * 64) + threadIdx.x;
-      const int r = idx / CPR, c = idx - r * CPR;
+      const int r = it * (NW * 64 / CPR) + threadIdx.x / CPR;
       const int m = m0 + r;
       if (m >= p.M) continue;
       const float4 lo = *reinterpret_cast<const float4*>(ct + r * BN + (((2 * c) ^ (r & 7)) << 2));
       const float4 hi = *reinterpret_cast<const float4*>(ct + r * BN + (((2 * c + 1) ^ (r & 7)) << 2));
       float v0[4] = {lo.x, lo.y, lo.z, lo.w}, v1[4] = {hi.x, hi.y, hi.z, hi.w};
-      epi4(p, bias, coff, m, n0 + c * 8, v0);
-      epi4(p, bias, coff, m, n0 + c * 8 + 4, v1);
+      epi4(p, bz0, coff, m, n0 + c * 8, v0);
+      epi4(p, bz1, coff, m, n0 + c * 8 + 4, v1);
     }
   } else {
     // direct form: lane holds C[m][n .. n+3] for each of its MFMA tiles
@@ -331,8 +336,179 @@ void gemm_bf16_nt_kernel(const FArgs p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         float v[4] = {acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha};
-        epi4(p, bias, coff, m, n0 + wc * (TN * 16) + j * 16 + ng, v);
+        const int n = n0 + wc * (TN * 16) + j * 16 + ng;
+        epi4(p, bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f), coff, m, n, v);
       }
+    }
+  }
+}
+
+// two ds_read_b128 of tile rows 0 / 16 from one base; NOT waited for here
+__device__ __forceinline__ void lds_read2(bf16x8 (&f)[2], unsigned base) {
+  asm volatile("ds_read_b128 %0, %2\n\t"
+               "ds_read_b128 %1, %2 offset:2048"
+               : "=&v"(f[0]), "=&v"(f[1])
+               : "v"(base)
+               : "memory");
+}
+
+// ---- 256 x 256 ping-pong kernel ----------------------------------------------------------------------------------------
+// 8 waves as 2 (M) x 4 (N), 128 x 64 per wave (8 x 4 MFMA tiles, 128 accumulator registers), BK = 64, two 64-KiB LDS
+// buffers, one workgroup per CU.  Half the L2 -> LDS bytes per FLOP of the 128^2 tile, which is what bounds that kernel
+// on the path's shapes (a streaming 50k-row activation operand: ~1.6 us per K-tile of load latency).
+//
+// A K-tile is worked in four phases, one C quadrant (64 x 32 per wave, 16 MFMAs over K = 64) each:
+//     phase = { issue this quadrant's ds_reads (+ a share of the NEXT K-tile's LDS-DMA) ; s_barrier ;
+//               lgkmcnt(0) ; 16 MFMAs ; s_barrier }
+// and the two wave halves (wr = 0 / 1: one wave of each on every SIMD) run ONE BARRIER APART, so while one half
+// multiplies the other half reads LDS -- the MFMA pipe and the LDS pipe of a SIMD are both busy without any
+// intra-wave software pipelining (cdna_hip_programming.md section 5, "8-phase template": same phase body; here the whole
+// next K-tile is requested at the top of the current one, the largest lead a 2-buffer scheme allows, because the
+// activation operand misses L2).
+//   P1: read a0 (4 row tiles x 2 k-halves), b0 (2 col tiles x 2)      stage A(t+1)     MFMA acc[0..3][0..1]
+//   P2: read b1                                                       stage B(t+1)     MFMA acc[0..3][2..3]
+//   P3: read a1 (over a0's registers)                                                   MFMA acc[4..7][2..3]
+//   P4: (b0 still in registers)  vmcnt(0) before the first barrier                      MFMA acc[4..7][0..1]
+// Hazards: tile t+1 is read (P1 of t+1) two barriers after every wave's own vmcnt(0); buffer (t+1)&1 is re-staged at P1/P2 of
+// tile t, four barriers after its last ds_read (P3 of tile t-1) was waited for by the later half.
+__global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) {
+  constexpr int BM = 256, BN = 256, NW = 8;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  // the whole 160-KiB LDS: a ring of THREE A tiles (the activation operand streams from HBM: two K-tiles of lead) and TWO B
+  // tiles (the weight panel is L2-resident: one K-tile of lead)
+  __shared__ __attribute__((aligned(1024))) char smem[3 * A_BYTES + 2 * B_BYTES];
+  char* const smem_b = smem + 3 * A_BYTES;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // XCD-aware tile id (as in the 128^2 kernel).  A persistent variant that requested the next output tile's first K-tiles
+  // before the epilogue measured no faster and costs registers; one output tile per workgroup it is.
+  const int nwg = p.ntm * p.ntn;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+  const int tid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  const int per_group = GROUP_M * p.ntn;
+  const int grp = tid / per_group, in_grp = tid - grp * per_group;
+  const int gm0 = grp * GROUP_M;
+  const int gsz = (p.ntm - gm0) < GROUP_M ? (p.ntm - gm0) : GROUP_M;
+  const int m0 = (gm0 + in_grp % gsz) * BM, n0 = (in_grp / gsz) * BN;
+  const int z = blockIdx.y;
+  const bf16_t* A = p.A + z * p.sA;
+  const bf16_t* B = p.B + z * p.sB;
+
+  const int frow = lane & 15;
+  const int sw = (lane >> 1) & 7;
+  const int foff0 = frow * 128 + (((lane >> 4)) ^ sw) * 16;
+  const int foff1 = frow * 128 + ((4 + (lane >> 4)) ^ sw) * 16;
+  const int nk = p.K / BK;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // first K-tiles: A(0) -> A slot 0, B(0) -> B slot 1, A(1) -> A slot 1
+  stage_tile<BM, NW>(A, p.lda, m0, p.M, 0, smem, wave, lane);
+  stage_tile<BN, NW>(B, p.ldb, n0, p.N, 0, smem_b + B_BYTES, wave, lane);
+  if (nk > 1) {
+    stage_tile<BM, NW>(A, p.lda, m0, p.M, BK, smem + A_BYTES, wave, lane);
+    wait_vmcnt<4>();                                // K-tile 0 landed; A(1), the 4 youngest loads, may still fly
+  } else {
+    wait_vmcnt<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();      // this half runs one barrier behind from here on
+
+#define PP_MFMA(AF, BF, I0, J0)                                                                                  \
+  do {                                                                                                           \
+    __builtin_amdgcn_s_barrier();                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                                               \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                             \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+          acc[I0 + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[kk][j], AF[kk][i], acc[I0 + i][J0 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    __builtin_amdgcn_s_barrier();                                                                                \
+  } while (0)
+
+  int sa = 0;                                       // A ring slot of tile t
+  for (int t = 0; t < nk; ++t) {
+    const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
+    const int sa2 = sa == 0 ? 2 : sa - 1;           // slot of tile t+2 == slot of tile t-1
+    const unsigned la = lds_off(smem + sa * A_BYTES + wr * (128 * 128));
+    const unsigned lb = lds_off(smem_b + ((t + 1) & 1) * B_BYTES + wc * (64 * 128));      // B(t) sits in slot (t+1)&1
+    bf16x8 af[2][4], b0f[2][2], b1f[2][2];
+    // ---- P1   (B's slot t&1 was last read at P2 of tile t-1; A's slot sa2 at P3 of tile t-1)
+    lds_read2(b0f[0], lb + foff0);
+    lds_read2(b0f[1], lb + foff1);
+    lds_read4(af[0], la + foff0);
+    lds_read4(af[1], la + foff1);
+    if (has1) stage_tile<BN, NW>(B, p.ldb, n0, p.N, (t + 1) * BK, smem_b + (t & 1) * B_BYTES, wave, lane);
+    PP_MFMA(af, b0f, 0, 0);
+    // ---- P2
+    lds_read2(b1f[0], lb + 4096 + foff0);
+    lds_read2(b1f[1], lb + 4096 + foff1);
+    if (has2) stage_tile<BM, NW>(A, p.lda, m0, p.M, (t + 2) * BK, smem + sa2 * A_BYTES, wave, lane);
+    PP_MFMA(af, b1f, 0, 2);
+    // ---- P3
+    lds_read4(af[0], la + 8192 + foff0);
+    lds_read4(af[1], la + 8192 + foff1);
+    PP_MFMA(af, b1f, 4, 2);
+    // ---- P4 (b0 still in registers): K-tile t+1 (A issued a K-tile ago, B at P1) must have landed; A(t+2), the 4 youngest
+    // loads, stays in flight
+    if (has2) wait_vmcnt<4>();
+    else if (has1) wait_vmcnt<0>();
+    PP_MFMA(af, b0f, 4, 0);
+    sa = sa == 2 ? 0 : sa + 1;
+  }
+#undef PP_MFMA
+  if (wr == 0) __builtin_amdgcn_s_barrier();      // re-join the halves: every ds_read of this output tile is done
+
+  // ---- epilogue: the fp32 tile goes through LDS one 128-row half at a time (whole-row 16-B accesses for bias / act'(pre) /
+  // residual / C, see the 128^2 kernel).  Code size matters here: epi4 carries every epilogue variant, and a fully unrolled
+  // four-quarter form of this loop (3x the instructions) measured 25 % slower end to end on K = 768 -- instruction fetch.
+  const int64_t coff = z * p.sC;
+  const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
+  float* ct = reinterpret_cast<float*>(smem);
+  const int g4 = lane >> 4;
+  const int c = threadIdx.x & 31;                   // this thread's 8-column chunk, the same in every pass
+  float4 bz0 = make_float4(0.f, 0.f, 0.f, 0.f), bz1 = bz0;
+  if (bias) {
+    bz0 = *reinterpret_cast<const float4*>(bias + n0 + c * 8);
+    bz1 = *reinterpret_cast<const float4*>(bias + n0 + c * 8 + 4);
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {            // unrolled: acc must be indexed statically (else it lives in scratch)
+    __syncthreads();
+    if (wr == half) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = i * 16 + frow;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int slot = (wc * 16 + j * 4 + g4) ^ (frow & 7);
+          *reinterpret_cast<float4*>(ct + r * BN + slot * 4) =
+              make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < 8; ++it) {                // 128 rows x 32 chunks / 512 threads
+      const int r = it * 16 + (threadIdx.x >> 5);
+      const int m = m0 + half * 128 + r;
+      if (m >= p.M) continue;
+      const float4 lo = *reinterpret_cast<const float4*>(ct + r * BN + (((2 * c) ^ (r & 7)) << 2));
+      const float4 hi = *reinterpret_cast<const float4*>(ct + r * BN + (((2 * c + 1) ^ (r & 7)) << 2));
+      float v0[4] = {lo.x, lo.y, lo.z, lo.w}, v1[4] = {hi.x, hi.y, hi.z, hi.w};
+      epi4(p, bz0, coff, m, n0 + c * 8, v0);
+      epi4(p, bz1, coff, m, n0 + c * 8 + 4, v1);
     }
   }
 }
@@ -384,8 +560,19 @@ int demo_gemm_bf16(const demo_gemm_desc& d, hipStream_t s) {
   const int nb = d.batch1 * d.batch2;
   // configuration code = tile*10 + stages: 1282 (128^2, 2 buffers, 2 workgroups/CU), 1283, 1284 (1 workgroup/CU),
   // 2562 (256^2, 8 waves), 2563 = 256x128 with 3 buffers
-  int cfg = g_force_tile ? g_force_tile : 1282;
-  if ((cfg == 2562) && d.N % 256) cfg = 1282;
+  int cfg = g_force_tile;
+  if (cfg == 0) {
+    // 256^2 ping-pong kernel when its coarser tiles still fill the 256 CUs evenly (or K is long enough that the main loop,
+    // ~1.4 PF/s marginal against ~1.1 for the 128^2 kernel, outweighs the last partial round); measured crossover on
+    // M = 49536: N = 2304 / 3072 always, N = 768 from K = 2048
+    cfg = 1282;
+    if (d.N % 256 == 0 && d.M >= 1024) {
+      const double rounds = (double)cdiv64(d.M, 256) * (d.N / 256) * nb / 256.0;
+      const double eff = rounds / (double)(int64_t)(rounds + 0.999999);
+      if (eff >= 0.85 || d.K >= 2048) cfg = 2566;
+    }
+  }
+  if ((cfg == 2562 || cfg == 2566) && d.N % 256) cfg = 1282;
 #define LAUNCH(BM_, BN_, WM_, WN_, NS_)                                                                                  \
   do {                                                                                                                   \
     p.ntm = (int)cdiv64(d.M, BM_);                                                                                       \
@@ -405,6 +592,11 @@ int demo_gemm_bf16(const demo_gemm_desc& d, hipStream_t s) {
     case 2563: LAUNCH(256, 128, 4, 2, 3); break;
     case 1283: LAUNCH(128, 128, 2, 2, 3); break;
     case 1284: LAUNCH(128, 128, 2, 2, 4); break;
+    case 2566:
+      p.ntm = (int)cdiv64(d.M, 256);
+      p.ntn = d.N / 256;
+      hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel, dim3((unsigned)(p.ntm * p.ntn), (unsigned)nb), dim3(512), 0, s, p);
+      break;
     case 1292: LAUNCH_RS(128, 128, 2, 2); break;
     case 2592: LAUNCH_RS(256, 128, 4, 2); break;
     default: LAUNCH(128, 128, 2, 2, 2); break;

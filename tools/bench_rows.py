@@ -59,3 +59,13 @@ for acc, lp in ((True, True), (True, False), (False, False)):
                                           dx_lp=dxlp if lp else None), a.reps)
     nbytes = M * D * (4 + 2 + 4 + (4 if acc else 0) + (2 if lp else 0))
     print(f"layernorm_bwd  acc={int(acc)} lp={int(lp)}: {ms * 1e3:7.1f} us  {nbytes / ms / 1e6:7.0f} GB/s")
+
+# self-attention forward / backward at the training shape (3B sequences x 12 heads x 129 tokens, head dim 64)
+Bn, L, H = 3 * a.batch, 129, 12
+qkv = (torch.randn(Bn * L, 3 * H * 64, device=dev) * 0.5).bfloat16()
+out, lse = ops.attention_fwd(qkv, Bn, L, H, save_lse=True)
+dout = torch.randn_like(out)
+ms = timeit(lambda: ops.attention_fwd(qkv, Bn, L, H, save_lse=True), a.reps)
+print(f"attention_fwd            : {ms * 1e3:7.1f} us  {Bn * L * H * 64 * 2 * 4 / ms / 1e6:7.0f} GB/s")
+ms = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, Bn, L, H), a.reps)
+print(f"attention_bwd            : {ms * 1e3:7.1f} us  {Bn * L * H * 64 * 2 * 8 / ms / 1e6:7.0f} GB/s")
