@@ -540,7 +540,13 @@ int demo_gemm_bf16_eligible(const demo_gemm_desc& d) {
 }
 
 static int g_force_tile = 0;   // test/bench hook: 128 or 256 forces a configuration, 0 = heuristic
-extern "C" int demo_gemm_force_tile(int t) { g_force_tile = t; return 0; }
+void demo_gemm_tn_force(int t);
+// 1280: only pins the weight-gradient (TN) product to its 128^2 form; 0 restores the heuristics of both
+extern "C" int demo_gemm_force_tile(int t) {
+  g_force_tile = t == 1280 ? 0 : t;
+  demo_gemm_tn_force(t == 1280 ? 128 : 0);
+  return 0;
+}
 
 int demo_gemm_bf16(const demo_gemm_desc& d, hipStream_t s) {
   FArgs p;

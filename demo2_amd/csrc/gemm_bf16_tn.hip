@@ -193,9 +193,196 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const TArgs p) {
   }
 }
 
+// ---- 256 x 256 ping-pong form ------------------------------------------------------------------------------------------
+// Same product, output tile 256 (Mo) x 256 (No) per 512-thread workgroup (8 waves as 2 x 4, 128 x 64 per wave), reduction
+// staged 32 rows at a time: a stage is 2 x 32 rows x 512 B = 32 KiB, the whole 160-KiB LDS is a ring of FIVE stages with
+// three of them in flight (both operands are activations streaming from HBM, ~96 KiB per CU of loads in the air).  Half the
+// L2 -> LDS bytes per FLOP of the 128^2 form, one workgroup per CU, the split-K factor chosen so that the grid is ~one
+// round of the 256 CUs.
+// A stage is one 32-deep MFMA step, worked in two phases (upper / lower 64 output rows of the wave, 16 MFMAs each):
+//     phase = { issue the phase's transposing LDS reads (+ the LDS-DMA of stage t+3 in the first phase) ; s_barrier ;
+//               MFMAs ; s_barrier }
+// with the two wave halves (wr = 0 / 1, one wave of each per SIMD) running one barrier apart: one half multiplies while
+// the other reads LDS (same scheme as the NT ping-pong kernel, gemm_bf16.hip).
+// Hazards: stage t+1 is waited for (counted vmcnt: stages t+2, t+3 stay in flight) before the first barrier of phase 2 of
+// stage t and first read two barriers later; slot (t+3)%5 is re-filled at phase 1 of stage t, its last reader was phase 2
+// of stage t-2.  512-B rows: the bank of a 16-B chunk depends on chunk&15 only, so the swizzle of the 128^2 form carries over.
+constexpr int PBM = 256, PBN = 256, PBK = 32, PSTAGES = 5;
+constexpr int POP_BYTES = PBK * 512;          // 16 KiB per operand per stage
+constexpr int PSTAGE_BYTES = 2 * POP_BYTES;
+
+// LDS-DMA of 32 rows x 256 columns (512 B per row): 2 rows per wave instruction, 2 instructions per wave
+__device__ __forceinline__ void pp_stage_op(const bf16_t* __restrict__ G, int64_t ld, int k0, int c0, char* lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int seg = j * 8 + wave;               // 1 KiB = 2 rows
+    const int r = seg * 2 + (lane >> 5);
+    const int c = (lane & 31) ^ (((r & 3) << 1) | (((r >> 3) & 1) << 3));
+    const bf16_t* src = G + (int64_t)(k0 + r) * ld + c0 + c * 8;
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(lds_tile + seg * 1024), 16, 0, 0);
+  }
+}
+// the partial stage at the end of the reduction: through registers, rows >= k_end read as zero (waits for its own loads)
+__device__ __forceinline__ void pp_stage_op_tail(const bf16_t* __restrict__ G, int64_t ld, int k0, int k_end, int c0, char* lds_tile,
+                                                 int wave, int lane) {
+  uint4 v[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int seg = j * 8 + wave;
+    const int r = seg * 2 + (lane >> 5);
+    const int c = (lane & 31) ^ (((r & 3) << 1) | (((r >> 3) & 1) << 3));
+    v[j] = make_uint4(0u, 0u, 0u, 0u);
+    if (k0 + r < k_end) v[j] = *reinterpret_cast<const uint4*>(G + (int64_t)(k0 + r) * ld + c0 + c * 8);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) *reinterpret_cast<uint4*>(lds_tile + (j * 8 + wave) * 1024 + lane * 16) = v[j];
+}
+
+__device__ __forceinline__ bf16x8 pp_tr_frag(const char* base, int off) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + off));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + off + 4 * 512));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <bool CS>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_tn_pp_kernel(const TArgs p) {
+  __shared__ __attribute__((aligned(1024))) char smem[PSTAGES * PSTAGE_BYTES];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  // work map: items = split-major list of (split, tile); XCD x (= blockIdx & 7) takes the x-th run of consecutive items, i.e.
+  // (mostly) one split: its ~32 co-resident workgroups read the same token rows of both operands through one L2.
+  const int tiles = p.ntm * p.ntn, items = tiles * p.splitk;
+  const int per = (items + 7) >> 3;
+  const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || item >= items) return;
+  const int split = item / tiles, tile = item - split * tiles;
+  const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
+  const int m0 = tm * PBM, n0 = tn * PBN;
+  const int ks = split * p.kper;
+  const int ke = min(p.Kr, ks + p.kper);
+  if (ks >= ke) return;
+  const int nk = (ke - ks + PBK - 1) / PBK;
+
+  // transposed-read addressing: lane (g, idx = 4q+pp): row 8g+q (second read +4 rows), 8-B piece pp of a 16-column block
+  const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
+  const int sw = (q << 1) | ((g & 1) << 3);
+  const int lbase = (8 * g + q) * 512 + ((pp & 1) << 3), csub = pp >> 1;
+  int aoff[8], boff[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) aoff[i] = lbase + ((((wr * 8 + i) * 2 + csub) ^ sw) << 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) boff[j] = POP_BYTES + lbase + ((((wc * 4 + j) * 2 + csub) ^ sw) << 4);
+
+  f32x4 acc[8][4], csum[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  csum[0] = csum[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // bias gradient: only the workgroups of the first column panel contribute (the others multiply by zeros)
+  const short one_or_zero = tn == 0 ? (short)0x3F80 : (short)0;
+  const bf16x8 ones = {one_or_zero, one_or_zero, one_or_zero, one_or_zero, one_or_zero, one_or_zero, one_or_zero, one_or_zero};
+
+  auto stage = [&](int t) {
+    char* buf = smem + (t % PSTAGES) * PSTAGE_BYTES;
+    const int k0 = ks + t * PBK;
+    if (k0 + PBK <= ke) {
+      pp_stage_op(p.A, p.lda, k0, m0, buf, wave, lane);
+      pp_stage_op(p.B, p.ldb, k0, n0, buf + POP_BYTES, wave, lane);
+    } else {
+      pp_stage_op_tail(p.A, p.lda, k0, ke, m0, buf, wave, lane);
+      pp_stage_op_tail(p.B, p.ldb, k0, ke, n0, buf + POP_BYTES, wave, lane);
+    }
+  };
+  stage(0);
+  if (nk > 1) stage(1);
+  if (nk > 2) stage(2);
+  if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();        // this half runs one barrier behind from here on
+
+  int slot = 0;
+  for (int t = 0; t < nk; ++t) {
+    const char* cur = smem + slot * PSTAGE_BYTES;
+    slot = slot + 1 == PSTAGES ? 0 : slot + 1;
+    bf16x8 af[4], bfr[4];
+    // ---- phase 1: output rows 0..63 of the wave
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = pp_tr_frag(cur, boff[j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = pp_tr_frag(cur, aoff[i]);
+    if (t + 3 < nk) stage(t + 3);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    if constexpr (CS) {
+      // bias gradient, branch-free (a wave-uniform `if` around an MFMA makes hipcc copy accumulators): wave wc sums output
+      // row tile wc of this phase, i.e. its A fragment times ones: one extra MFMA per 16
+      const bf16x8 asel = wc == 0 ? af[0] : (wc == 1 ? af[1] : (wc == 2 ? af[2] : af[3]));
+      csum[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asel, ones, csum[0], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: output rows 64..127 of the wave; stage t+1 must have landed before the first barrier
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = pp_tr_frag(cur, aoff[4 + i]);
+    if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[4 + i][j], 0, 0, 0);
+    if constexpr (CS) {
+      const bf16x8 asel = wc == 0 ? af[0] : (wc == 1 ? af[1] : (wc == 2 ? af[2] : af[3]));
+      csum[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asel, ones, csum[1], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();        // re-join the halves
+
+  if constexpr (CS) {
+    // csum[ii]: D[row = m_local = 4g + reg][any column]: output row tile ii*4 + wc of this wave's half
+    if (idx == 0) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(p.colsum + m0 + wr * 128 + (ii * 4 + wc) * 16 + 4 * g + r, csum[ii][r]);
+    }
+  }
+  // D[row = m_local = 4g + reg][col = n_local = lane & 15]: per register 4 rows x 64 contiguous bytes
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wc * 64 + j * 16 + idx;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wr * 128 + i * 16 + 4 * g + r;
+        float* c = p.C + (int64_t)m * p.ldc + n;
+        const float v = acc[i][j][r] * p.alpha;
+        if (p.use_atomics) atomicAdd(c, v);
+        else *c = p.accumulate ? *c + v : v;
+      }
+    }
+  }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
+
+static int g_tn_force = 0;     // bench hook (shared with demo_gemm_force_tile): 128 forces the 128^2 form
+void demo_gemm_tn_force(int t) { g_tn_force = t; }
 
 extern "C" int demo_gemm_tn_bf16(const void* A, const void* B, float* C, int32_t Mo, int32_t No, int32_t Kr, int64_t lda, int64_t ldb,
                                  int64_t ldc, float alpha, int32_t accumulate, float* colsum, void* stream) {
@@ -206,6 +393,30 @@ extern "C" int demo_gemm_tn_bf16(const void* A, const void* B, float* C, int32_t
   TArgs p;
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
   p.Mo = Mo; p.No = No; p.Kr = Kr; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.alpha = alpha;
+  if (g_tn_force != 128 && Mo % PBM == 0 && No % PBN == 0 && Kr >= 2048) {
+    // 256^2 ping-pong form: split the reduction so that the grid is about one round of the 256 CUs
+    p.ntm = Mo / PBM; p.ntn = No / PBN;
+    const int tiles = p.ntm * p.ntn;
+    const int kstages = (Kr + PBK - 1) / PBK;
+    int splitk = tiles >= 256 ? 1 : 256 / tiles;
+    if (splitk > kstages / 16) splitk = kstages / 16 > 0 ? kstages / 16 : 1;      // at least 16 stages per workgroup
+    const int per = (kstages + splitk - 1) / splitk;
+    p.kper = per * PBK;
+    p.splitk = (kstages + per - 1) / per;
+    p.use_atomics = p.splitk > 1;
+    p.accumulate = accumulate;
+    p.colsum = colsum;
+    p.part_m = 0;
+    if (p.use_atomics && !accumulate) {
+      hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)No * sizeof(float), (size_t)Mo, s);
+      if (e != hipSuccess) DEMO_FAIL(-2, "demo_gemm_tn_bf16: memset failed: %s", hipGetErrorString(e));
+    }
+    const unsigned nwg = 8u * (unsigned)((tiles * p.splitk + 7) / 8);
+    if (colsum) hipLaunchKernelGGL(gemm_bf16_tn_pp_kernel<true>, dim3(nwg), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL(gemm_bf16_tn_pp_kernel<false>, dim3(nwg), dim3(512), 0, s, p);
+    DEMO_LAUNCH_CHECK("demo_gemm_tn_bf16(256)");
+    return 0;
+  }
   p.ntm = Mo / BM; p.ntn = No / BN;
   const int tiles = p.ntm * p.ntn;
   const int ktiles = (Kr + BK - 1) / BK;
