@@ -115,6 +115,150 @@ __device__ __forceinline__ void epi4(const FArgs& p, const float4 b4, int64_t co
   }
 }
 
+// ---- row-major epilogue of the LDS-staged forms ------------------------------------------------------------------------
+// A thread owns one 8-column chunk (column n) and NIT rows r0, r0+RSTEP, ... of the fp32 tile image `ct` (row stride BN_
+// floats, 16-B slots XOR-swizzled with row&7).  Rows are handled G at a time (4; 2 in the 256^2 kernel, whose accumulators are still live): first every global operand
+// the epilogue consumes for the G rows is requested (act'(pre) source, residual, old C), then the rows are finished one by one.  The
+// per-row form (load inside the row's arithmetic) paid one dependent HBM/L2 latency per row: the dY.W^T * act'(pre) product
+// of the MLP backward ran at 456 TF against 870 for the same shape with a plain epilogue.  Stores are 16 B per thread and
+// row for bf16 outputs (8 columns), 2 x 16 B for fp32.
+struct EpiOps {
+  float4 pre0, pre1, res0, res1, old0, old1;
+};
+__device__ __forceinline__ void bf16x8_to_f32(const uint4 r, float4& lo, float4& hi) {
+  lo = make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                   __uint_as_float(r.y & 0xffff0000u));
+  hi = make_float4(__uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u), __uint_as_float(r.w << 16),
+                   __uint_as_float(r.w & 0xffff0000u));
+}
+__device__ __forceinline__ uint4 f32x8_to_bf16(const float (&v)[8]) {
+  uint4 r;
+  r.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  r.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  r.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+  r.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  return r;
+}
+// ACT / GK: activation and activation-gradient kinds as COMPILE-TIME constants (-1 = read them from p at run time).  With both
+// as run-time switches every row instance carried QuickGELU and erf-GELU, forward and derivative: 157 KB of code for the
+// 256^2 kernel against a 64-KB instruction cache, and its epilogue ran at instruction-fetch speed.
+template <int ACT, int GK>
+__device__ __forceinline__ void epi8_finish(const FArgs& p, const float4 bz0, const float4 bz1, const EpiOps& x, int64_t ci, float (&v)[8]) {
+  const int act = ACT >= 0 ? ACT : p.act;
+  const int gk = GK >= 0 ? GK : p.act_grad_kind;
+  const bool has_pre = GK >= 0 ? GK != DEMO_ACT_NONE : p.pre != nullptr;
+  v[0] += bz0.x; v[1] += bz0.y; v[2] += bz0.z; v[3] += bz0.w;
+  v[4] += bz1.x; v[5] += bz1.y; v[6] += bz1.z; v[7] += bz1.w;
+  if (p.pre_out) {
+    if (p.dtC == DEMO_F32) {
+      float* q = reinterpret_cast<float*>(p.pre_out) + ci;
+      *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(q + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.pre_out) + ci) = f32x8_to_bf16(v);
+    }
+  }
+  if (act != DEMO_ACT_NONE) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e], act);
+  }
+  if (has_pre) {
+    const float pr[8] = {x.pre0.x, x.pre0.y, x.pre0.z, x.pre0.w, x.pre1.x, x.pre1.y, x.pre1.z, x.pre1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= act_grad(pr[e], gk);
+  }
+  if (p.residual) {
+    v[0] += x.res0.x; v[1] += x.res0.y; v[2] += x.res0.z; v[3] += x.res0.w;
+    v[4] += x.res1.x; v[5] += x.res1.y; v[6] += x.res1.z; v[7] += x.res1.w;
+  }
+  if (p.dtC == DEMO_F32) {
+    float* c = reinterpret_cast<float*>(p.C) + ci;
+    if (p.accumulate) {
+      v[0] += x.old0.x; v[1] += x.old0.y; v[2] += x.old0.z; v[3] += x.old0.w;
+      v[4] += x.old1.x; v[5] += x.old1.y; v[6] += x.old1.z; v[7] += x.old1.w;
+    }
+    *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + ci) = f32x8_to_bf16(v);
+  }
+}
+template <int NIT, int RSTEP, int BN_, int G, int ACT, int GK>
+__device__ __forceinline__ void epi_rows_k(const FArgs& p, const float* __restrict__ ct, int r0, int mrow0, int n, int c, const float4 bz0,
+                                           const float4 bz1, int64_t coff) {
+  const bool has_pre = GK >= 0 ? GK != DEMO_ACT_NONE : p.pre != nullptr;
+  static_assert(NIT % G == 0, "rows are finished G at a time");
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int g0 = 0; g0 < NIT; g0 += G) {
+    EpiOps x[G];
+    int64_t ci[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      int m = mrow0 + r0 + (g0 + u) * RSTEP;
+      m = m < p.M ? m : p.M - 1;                      // clamped for the loads; the store below is guarded
+      ci[u] = coff + (int64_t)m * p.ldc + n;
+      x[u].pre0 = x[u].pre1 = x[u].res0 = x[u].res1 = x[u].old0 = x[u].old1 = z4;
+    }
+    if (has_pre) {
+      if (p.dtPre == DEMO_BF16) {
+        uint4 raw[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) raw[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.pre) + ci[u]);
+#pragma unroll
+        for (int u = 0; u < G; ++u) bf16x8_to_f32(raw[u], x[u].pre0, x[u].pre1);
+      } else {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          x[u].pre0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.pre) + ci[u]);
+          x[u].pre1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.pre) + ci[u] + 4);
+        }
+      }
+    }
+    if (p.residual) {
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        x[u].res0 = *reinterpret_cast<const float4*>(p.residual + ci[u]);
+        x[u].res1 = *reinterpret_cast<const float4*>(p.residual + ci[u] + 4);
+      }
+    }
+    if (p.accumulate && p.dtC == DEMO_F32) {
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        x[u].old0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.C) + ci[u]);
+        x[u].old1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.C) + ci[u] + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int r = r0 + (g0 + u) * RSTEP;
+      if (mrow0 + r >= p.M) continue;
+      const float4 lo = *reinterpret_cast<const float4*>(ct + r * BN_ + (((2 * c) ^ (r & 7)) << 2));
+      const float4 hi = *reinterpret_cast<const float4*>(ct + r * BN_ + (((2 * c + 1) ^ (r & 7)) << 2));
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      epi8_finish<ACT, GK>(p, bz0, bz1, x[u], ci[u], v);
+    }
+  }
+}
+// one compact copy per (activation, activation-gradient) pair the path uses; anything else takes the run-time form
+template <int NIT, int RSTEP, int BN_, int G>
+__device__ __forceinline__ void epi_rows(const FArgs& p, const float* __restrict__ ct, int r0, int mrow0, int n, int c, const float4 bz0,
+                                         const float4 bz1, int64_t coff) {
+  const int gk = p.pre ? p.act_grad_kind : DEMO_ACT_NONE;
+  if (p.act == DEMO_ACT_NONE && gk == DEMO_ACT_NONE)
+    epi_rows_k<NIT, RSTEP, BN_, G, DEMO_ACT_NONE, DEMO_ACT_NONE>(p, ct, r0, mrow0, n, c, bz0, bz1, coff);
+  else if (p.act == DEMO_ACT_QUICKGELU && gk == DEMO_ACT_NONE)
+    epi_rows_k<NIT, RSTEP, BN_, G, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE>(p, ct, r0, mrow0, n, c, bz0, bz1, coff);
+  else if (p.act == DEMO_ACT_NONE && gk == DEMO_ACT_QUICKGELU)
+    epi_rows_k<NIT, RSTEP, BN_, G, DEMO_ACT_NONE, DEMO_ACT_QUICKGELU>(p, ct, r0, mrow0, n, c, bz0, bz1, coff);
+  else if (p.act == DEMO_ACT_GELU && gk == DEMO_ACT_NONE)
+    epi_rows_k<NIT, RSTEP, BN_, G, DEMO_ACT_GELU, DEMO_ACT_NONE>(p, ct, r0, mrow0, n, c, bz0, bz1, coff);
+  else if (p.act == DEMO_ACT_NONE && gk == DEMO_ACT_GELU)
+    epi_rows_k<NIT, RSTEP, BN_, G, DEMO_ACT_NONE, DEMO_ACT_GELU>(p, ct, r0, mrow0, n, c, bz0, bz1, coff);
+  else
+    epi_rows_k<NIT, RSTEP, BN_, G, -1, -1>(p, ct, r0, mrow0, n, c, bz0, bz1, coff);
+}
+
 __device__ __forceinline__ unsigned lds_off(const char* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
@@ -315,17 +459,7 @@ void gemm_bf16_nt_kernel(const FArgs p) {
       bz0 = *reinterpret_cast<const float4*>(bias + n0 + c * 8);
       bz1 = *reinterpret_cast<const float4*>(bias + n0 + c * 8 + 4);
     }
-#pragma unroll 4
-    for (int it = 0; it < (BM * CPR) / (NW * 64); ++it) {
-      const int r = it * (NW * 64 / CPR) + threadIdx.x / CPR;
-      const int m = m0 + r;
-      if (m >= p.M) continue;
-      const float4 lo = *reinterpret_cast<const float4*>(ct + r * BN + (((2 * c) ^ (r & 7)) << 2));
-      const float4 hi = *reinterpret_cast<const float4*>(ct + r * BN + (((2 * c + 1) ^ (r & 7)) << 2));
-      float v0[4] = {lo.x, lo.y, lo.z, lo.w}, v1[4] = {hi.x, hi.y, hi.z, hi.w};
-      epi4(p, bz0, coff, m, n0 + c * 8, v0);
-      epi4(p, bz1, coff, m, n0 + c * 8 + 4, v1);
-    }
+    epi_rows<(BM * CPR) / (NW * 64), NW * 64 / CPR, BN, 4>(p, ct, threadIdx.x / CPR, m0, n0 + c * 8, c, bz0, bz1, coff);
   } else {
     // direct form: lane holds C[m][n .. n+3] for each of its MFMA tiles
     const int ng = (lane >> 4) * 4;
@@ -410,6 +544,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // (De-phasing the first round of workgroups with s_sleep, so that CUs do not reach their store-heavy epilogues together,
+  // was tried -- 2/4/8 phase groups, 7..17 us apart -- and measured 2..6 % slower on the training step.)
   // first K-tiles: A(0) -> A slot 0, B(0) -> B slot 1, A(1) -> A slot 1
   stage_tile<BM, NW>(A, p.lda, m0, p.M, 0, smem, wave, lane);
   stage_tile<BN, NW>(B, p.ldb, n0, p.N, 0, smem_b + B_BYTES, wave, lane);
@@ -499,17 +635,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
       }
     }
     __syncthreads();
-#pragma unroll 4
-    for (int it = 0; it < 8; ++it) {                // 128 rows x 32 chunks / 512 threads
-      const int r = it * 16 + (threadIdx.x >> 5);
-      const int m = m0 + half * 128 + r;
-      if (m >= p.M) continue;
-      const float4 lo = *reinterpret_cast<const float4*>(ct + r * BN + (((2 * c) ^ (r & 7)) << 2));
-      const float4 hi = *reinterpret_cast<const float4*>(ct + r * BN + (((2 * c + 1) ^ (r & 7)) << 2));
-      float v0[4] = {lo.x, lo.y, lo.z, lo.w}, v1[4] = {hi.x, hi.y, hi.z, hi.w};
-      epi4(p, bz0, coff, m, n0 + c * 8, v0);
-      epi4(p, bz1, coff, m, n0 + c * 8 + 4, v1);
-    }
+    epi_rows<8, 16, BN, 2>(p, ct, threadIdx.x >> 5, m0 + half * 128, n0 + c * 8, c, bz0, bz1, coff);   // 128 rows x 32 chunks / 512 threads
   }
 }
 
@@ -529,6 +655,8 @@ int demo_gemm_bf16_eligible(const demo_gemm_desc& d) {
   if (d.act_grad_pre && !al16(d.act_grad_pre)) return 0;
   if (d.pre_out && !al16(d.pre_out)) return 0;
   if (d.accumulate && d.dtC != DEMO_F32) return 0;
+  // the row-major epilogue moves 8 columns (16 B of bf16) per access
+  if ((d.dtC == DEMO_BF16 || (d.act_grad_pre && d.dtPre == DEMO_BF16)) && d.c_rs % 8) return 0;
   if (d.batch1 != 1) {
     if (d.batch2 != 1) return 0;               // single-level batching only
   }
