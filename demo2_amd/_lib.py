@@ -56,14 +56,14 @@ PROTOTYPES = {
     "demo_layernorm_fwd": [_P, _P, _P, _F, _P, _I, _P, _P, _I, _I, _P],
     "demo_layernorm_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P],
     "demo_layernorm_bwd_workspace": [_I, _I],
-    "demo_adam_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _P],
+    "demo_adam_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _P, _P],
     "demo_batchnorm_fwd": [_P, _P, _P, _P, _P, _I, _F, _F, _P, _I, _P, _P, _I, _I, _I, _I, _I, _L, _L, _P, _P],
     "demo_attention_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "demo_pife_pool_cat": [_P, _I, _P, _I, _I, _I, _P],
     "demo_set_token0": [_P, _I, _P, _L, _I, _I, _I, _P],
     "demo_get_token0": [_P, _I, _P, _L, _I, _I, _I, _P],
-    "demo_hdm_softmax_pool": [_P, _L, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _U64, _P],
-    "demo_hdm_softmax_pool_bwd": [_P, _P, _P, _P, _I, _P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _U64, _P],
+    "demo_hdm_softmax_pool": [_P, _L, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _U64, _P, _P],
+    "demo_hdm_softmax_pool_bwd": [_P, _P, _P, _P, _I, _P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _U64, _P, _P],
     "demo_hdm_vbias_bwd": [_P, _P, _L, _P, _P, _P, _I, _I, _I, _P],
     "demo_atmoe_gate_softmax_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "demo_gemm_tn_bf16": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _F, _I, _P, _P],

@@ -9,7 +9,11 @@ int demo_gemm_bf16(const demo_gemm_desc& d, hipStream_t s);
 
 extern "C" int demo_abi_version(void) { return 1; }
 extern "C" const char* demo_last_error(void) { return g_demo_err; }
-extern "C" int demo_gemm_path(const demo_gemm_desc* d) { return d ? demo_gemm_bf16_eligible(*d) : 0; }
+int demo_gemm_bf16_config(const demo_gemm_desc& d);
+extern "C" int demo_gemm_path(const demo_gemm_desc* d) {
+  if (!d || !demo_gemm_bf16_eligible(*d)) return 0;
+  return demo_gemm_bf16_config(*d) == 2566 ? 2 : 1;
+}
 extern "C" int demo_gemm_desc_size(void) { return (int)sizeof(demo_gemm_desc); }
 
 extern "C" int demo_gemm(const demo_gemm_desc* dp, void* stream) {

@@ -212,8 +212,10 @@ __global__ __launch_bounds__(256) void hdm_softmax_pool_bwd_kernel(const float* 
                                                                    const float* __restrict__ probs, const T* __restrict__ tok,
                                                                    const float* __restrict__ pooled, const float* __restrict__ psum,
                                                                    float* __restrict__ dS, int64_t ldS, float* __restrict__ dtok,
-                                                                   int Bs, int L, int C, int Hh, float p_drop, uint64_t seed) {
+                                                                   int Bs, int L, int C, int Hh, float p_drop, uint64_t seed,
+                                                                   const uint64_t* __restrict__ seed_dev) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  if (seed_dev) seed += *seed_dev;            // same device-resident seed part as the forward read
   const int b = blockIdx.x, m = blockIdx.y;
   const int L3 = 3 * L;
   float* dpl = sm;                          // [4][Hh][C]
@@ -431,7 +433,13 @@ __global__ __launch_bounds__(256) void tokens_grad_kernel(const float* __restric
 __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, bf16_t* __restrict__ shadow, int64_t n4, float lr,
                                                         float b1, float b2, float eps, float wd, float bc1, float bc2_rsqrt,
-                                                        int zero_grad) {
+                                                        int zero_grad, const float* __restrict__ hyper) {
+  if (hyper) {              // {lr, update count t} in device memory: a captured step replays with fresh values
+    lr = hyper[0];
+    const float t = hyper[1];
+    bc1 = 1.f - powf(b1, t);
+    bc2_rsqrt = rsqrtf(1.f - powf(b2, t));
+  }
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 pv = *reinterpret_cast<const float4*>(p + i * 4);
     const float4 gv = *reinterpret_cast<const float4*>(g + i * 4);
@@ -459,14 +467,14 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, f
 }  // namespace
 
 extern "C" int demo_adam_step(float* p, float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1, float beta2,
-                              float eps, float weight_decay, int32_t step, int32_t zero_grad, void* stream) {
-  DEMO_REQUIRE(n % 4 == 0 && step >= 1, "demo_adam_step: n must be a multiple of 4 and step >= 1");
-  const float bc1 = 1.f - powf(beta1, (float)step);
-  const float bc2 = 1.f - powf(beta2, (float)step);
+                              float eps, float weight_decay, int32_t step, int32_t zero_grad, const float* hyper_dev, void* stream) {
+  DEMO_REQUIRE(n % 4 == 0 && (step >= 1 || hyper_dev), "demo_adam_step: n must be a multiple of 4 and step >= 1");
+  const float bc1 = step >= 1 ? 1.f - powf(beta1, (float)step) : 1.f;
+  const float bc2 = step >= 1 ? 1.f - powf(beta2, (float)step) : 1.f;
   int64_t grid = cdiv64(n / 4, 256);
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow_bf16, n / 4, lr,
-                     beta1, beta2, eps, weight_decay, bc1, 1.f / sqrtf(bc2), zero_grad);
+                     beta1, beta2, eps, weight_decay, bc1, 1.f / sqrtf(bc2), zero_grad, hyper_dev);
   DEMO_LAUNCH_CHECK("demo_adam_step");
   return 0;
 }
@@ -527,7 +535,8 @@ extern "C" int demo_atmoe_gate_softmax_bwd(const float* dgates, const float* gat
 
 extern "C" int demo_hdm_softmax_pool_bwd(const float* dpooled, const float* dpsum, const float* probs, const void* tokens, int32_t dt,
                                          const float* pooled, const float* psum, float* dS, int64_t ldS, float* dtokens, int32_t Bs,
-                                         int32_t L, int32_t C, int32_t Hh, float p_drop, uint64_t seed, void* stream) {
+                                         int32_t L, int32_t C, int32_t Hh, float p_drop, uint64_t seed, const uint64_t* seed_dev,
+                                         void* stream) {
   DEMO_REQUIRE(Hh >= 1 && Hh <= HH_MAX && C <= 1024 && C % 4 == 0 && ldS >= 7 * Hh, "demo_hdm_softmax_pool_bwd: unsupported shape");
   const size_t shm = sizeof(float) * (4 * (size_t)Hh * C + 8 * HH_MAX);
   DEMO_REQUIRE(shm <= 160 * 1024, "demo_hdm_softmax_pool_bwd: needs %zu B of LDS", shm);
@@ -539,10 +548,10 @@ extern "C" int demo_hdm_softmax_pool_bwd(const float* dpooled, const float* dpsu
   dim3 grid(Bs, 3);
   if (dt == DEMO_BF16)
     hipLaunchKernelGGL(hdm_softmax_pool_bwd_kernel<bf16_t>, grid, dim3(256), shm, s, dpooled, dpsum, probs, (const bf16_t*)tokens, pooled,
-                       psum, dS, ldS, dtokens, Bs, L, C, Hh, p_drop, seed);
+                       psum, dS, ldS, dtokens, Bs, L, C, Hh, p_drop, seed, seed_dev);
   else
     hipLaunchKernelGGL(hdm_softmax_pool_bwd_kernel<float>, grid, dim3(256), shm, s, dpooled, dpsum, probs, (const float*)tokens, pooled,
-                       psum, dS, ldS, dtokens, Bs, L, C, Hh, p_drop, seed);
+                       psum, dS, ldS, dtokens, Bs, L, C, Hh, p_drop, seed, seed_dev);
   DEMO_LAUNCH_CHECK("demo_hdm_softmax_pool_bwd");
   return 0;
 }

@@ -28,8 +28,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void hdm_softmax_pool_kernel(const float* __restrict__ S, int64_t ldS, const T* __restrict__ tok,
                                                                float* __restrict__ pooled, float* __restrict__ psum,
                                                                float* __restrict__ probs, float* __restrict__ probs_post, int Bs, int L, int C, int Hh,
-                                                               float p_drop, uint64_t seed) {
+                                                               float p_drop, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  if (seed_dev) seed += *seed_dev;            // device-resident part of the seed: advances between replays of a captured step
   const int b = blockIdx.x, br = blockIdx.y;
   const int ns = c_nstreams[br];
   const int Lk = ns * L, L3 = 3 * L;
@@ -169,7 +170,8 @@ __global__ __launch_bounds__(256) void atmoe_gate_softmax_kernel(const float* __
 }  // namespace
 
 extern "C" int demo_hdm_softmax_pool(const float* S, int64_t ldS, const void* tokens, int32_t dt, float* pooled, float* psum, float* probs, float* probs_post,
-                                     int32_t Bs, int32_t L, int32_t C, int32_t Hh, float p_drop, uint64_t seed, void* stream) {
+                                     int32_t Bs, int32_t L, int32_t C, int32_t Hh, float p_drop, uint64_t seed, const uint64_t* seed_dev,
+                                     void* stream) {
   DEMO_REQUIRE(Hh >= 1 && Hh <= HH_MAX, "demo_hdm_softmax_pool: heads=%d unsupported (<=%d)", Hh, HH_MAX);
   DEMO_REQUIRE(C % 4 == 0 && C / 4 <= 256 && C >= 4, "demo_hdm_softmax_pool: C=%d unsupported", C);
   DEMO_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "demo_hdm_softmax_pool: p_drop=%f", p_drop);
@@ -179,9 +181,9 @@ extern "C" int demo_hdm_softmax_pool(const float* S, int64_t ldS, const void* to
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(Bs, 7);
   if (dt == DEMO_BF16)
-    hipLaunchKernelGGL(hdm_softmax_pool_kernel<bf16_t>, grid, dim3(256), shm, s, S, ldS, (const bf16_t*)tokens, pooled, psum, probs, probs_post, Bs, L, C, Hh, p_drop, seed);
+    hipLaunchKernelGGL(hdm_softmax_pool_kernel<bf16_t>, grid, dim3(256), shm, s, S, ldS, (const bf16_t*)tokens, pooled, psum, probs, probs_post, Bs, L, C, Hh, p_drop, seed, seed_dev);
   else
-    hipLaunchKernelGGL(hdm_softmax_pool_kernel<float>, grid, dim3(256), shm, s, S, ldS, (const float*)tokens, pooled, psum, probs, probs_post, Bs, L, C, Hh, p_drop, seed);
+    hipLaunchKernelGGL(hdm_softmax_pool_kernel<float>, grid, dim3(256), shm, s, S, ldS, (const float*)tokens, pooled, psum, probs, probs_post, Bs, L, C, Hh, p_drop, seed, seed_dev);
   DEMO_LAUNCH_CHECK("demo_hdm_softmax_pool");
   return 0;
 }

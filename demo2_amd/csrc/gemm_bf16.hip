@@ -676,6 +676,25 @@ extern "C" int demo_gemm_force_tile(int t) {
   return 0;
 }
 
+// kernel configuration the dispatcher will use for an eligible descriptor (also reported through demo_gemm_path)
+int demo_gemm_bf16_config(const demo_gemm_desc& d) {
+  const int nb = d.batch1 * d.batch2;
+  int cfg = g_force_tile;
+  if (cfg == 0) {
+    // 256^2 ping-pong kernel when its coarser tiles still fill the 256 CUs evenly (or K is long enough that the main loop,
+    // ~1.4 PF/s marginal against ~1.1 for the 128^2 kernel, outweighs the last partial round); measured crossover on
+    // M = 49536: N = 2304 / 3072 always, N = 768 from K = 2048
+    cfg = 1282;
+    if (d.N % 256 == 0 && d.M >= 1024) {
+      const double rounds = (double)cdiv64(d.M, 256) * (d.N / 256) * nb / 256.0;
+      const double eff = rounds / (double)(int64_t)(rounds + 0.999999);
+      if (eff >= 0.85 || d.K >= 2048) cfg = 2566;
+    }
+  }
+  if ((cfg == 2562 || cfg == 2566) && d.N % 256) cfg = 1282;
+  return cfg;
+}
+
 int demo_gemm_bf16(const demo_gemm_desc& d, hipStream_t s) {
   FArgs p;
   p.A = reinterpret_cast<const bf16_t*>(d.A);
@@ -694,19 +713,7 @@ int demo_gemm_bf16(const demo_gemm_desc& d, hipStream_t s) {
   const int nb = d.batch1 * d.batch2;
   // configuration code = tile*10 + stages: 1282 (128^2, 2 buffers, 2 workgroups/CU), 1283, 1284 (1 workgroup/CU),
   // 2562 (256^2, 8 waves), 2563 = 256x128 with 3 buffers
-  int cfg = g_force_tile;
-  if (cfg == 0) {
-    // 256^2 ping-pong kernel when its coarser tiles still fill the 256 CUs evenly (or K is long enough that the main loop,
-    // ~1.4 PF/s marginal against ~1.1 for the 128^2 kernel, outweighs the last partial round); measured crossover on
-    // M = 49536: N = 2304 / 3072 always, N = 768 from K = 2048
-    cfg = 1282;
-    if (d.N % 256 == 0 && d.M >= 1024) {
-      const double rounds = (double)cdiv64(d.M, 256) * (d.N / 256) * nb / 256.0;
-      const double eff = rounds / (double)(int64_t)(rounds + 0.999999);
-      if (eff >= 0.85 || d.K >= 2048) cfg = 2566;
-    }
-  }
-  if ((cfg == 2562 || cfg == 2566) && d.N % 256) cfg = 1282;
+  const int cfg = demo_gemm_bf16_config(d);
 #define LAUNCH(BM_, BN_, WM_, WN_, NS_)                                                                                  \
   do {                                                                                                                   \
     p.ntm = (int)cdiv64(d.M, BM_);                                                                                       \

@@ -160,7 +160,8 @@ def hdm_forward(m, tokens: Tensor, ori: Tensor, B: int, training: bool, tape: Op
     S = ops.gemm(tokens, U, out_dtype=torch.float32)                              # (3B*L, NC_PAD)
     p_drop = g.hdm_dropout if training else 0.0
     seed = m.next_seed() if p_drop > 0 else 0
-    pooled, psum, probs = ops.hdm_softmax_pool(S, tokens, B, L, C, Hh, NC_PAD, p_drop, seed, save_probs=tape is not None)
+    pooled, psum, probs = ops.hdm_softmax_pool(S, tokens, B, L, C, Hh, NC_PAD, p_drop, seed, save_probs=tape is not None,
+                                               seed_dev=m.seed_dev if p_drop > 0 else None)
     # per-head value projection o[b,br,h*64+e] = Wv_h pooled[b,br,h,:] (+ bv * psum)
     o = torch.empty(B, 7, C, device=dev, dtype=torch.float32)
     ops.gemm_raw(pooled, P.flat, o, B, 64, C, 7 * Hh * C, 1, C, 1, 7 * C, b_off=o_w + 2 * C * C,
@@ -173,7 +174,7 @@ def hdm_forward(m, tokens: Tensor, ori: Tensor, B: int, training: bool, tape: Op
                  bias_off=P.off(f + "r.out_proj.bias"), batch1=7, sA=(C, 0), sB=(sbr_ow, 0), sC=(C, 0), sBias=(sbr_ob, 0))
     if tape is not None:
         tape.d.update(hdm_q=q, hdm_U=U, hdm_probs=probs, hdm_pooled=pooled, hdm_psum=psum, hdm_o=o, hdm_seed=seed,
-                      hdm_pdrop=p_drop, tokens=tokens)
+                      hdm_seed_dev=m.seed_dev if p_drop > 0 else None, hdm_pdrop=p_drop, tokens=tokens)
     return feats
 
 

@@ -143,6 +143,7 @@ class DeMo(_Holder):
         self.ptab, self.stab = FlatTable(), FlatTable()
         self._ws: Dict[str, torch.Tensor] = {}
         self._seed = 0x5EED
+        self.seed_dev = None             # optional 1-element int64 CUDA tensor added to the dropout seed on the device (graph replay)
         self._plist = None
         self._anchor = None
         self._frozen = None
@@ -330,13 +331,15 @@ class DeMo(_Holder):
         if sentinel.grad is None or not (lo <= sentinel.grad.data_ptr() < hi):
             self.attach_grads(zero=True)
 
-    def adam_step(self, m, v, lr, beta1, beta2, eps, weight_decay, t):
-        """Fused flat Adam over (flat params, flat grads); also refreshes the bf16 shadow and clears the gradients."""
+    def adam_step(self, m, v, lr, beta1, beta2, eps, weight_decay, t, hyper_dev=None):
+        """Fused flat Adam over (flat params, flat grads); also refreshes the bf16 shadow and clears the gradients.
+        hyper_dev: device-resident {lr, bias corrections} (see ops.adam_step) for graph-captured steps."""
         P = self.ptab
         lp = self.compute_dtype == torch.bfloat16
         if lp and P.shadow is None:
             P.shadow = torch.empty(P.flat.numel(), device=P.flat.device, dtype=torch.bfloat16)
-        ops.adam_step(P.flat, self.grad_buffer(), m, v, P.shadow if lp else None, lr, beta1, beta2, eps, weight_decay, t, zero_grad=True)
+        ops.adam_step(P.flat, self.grad_buffer(), m, v, P.shadow if lp else None, lr, beta1, beta2, eps, weight_decay, t, zero_grad=True,
+                      hyper_dev=hyper_dev)
         self._refresh_derived()
         P.shadow_version = (self._param_version(), bool(self.training), self.compute_dtype)
 

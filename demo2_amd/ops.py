@@ -260,14 +260,17 @@ _LN_WS = {}
 
 
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, shadow: Optional[Tensor], lr: float, beta1: float, beta2: float, eps: float,
-              weight_decay: float, step: int, zero_grad: bool = True):
+              weight_decay: float, step: int, zero_grad: bool = True, hyper_dev: Optional[Tensor] = None):
     """Fused flat Adam (torch.optim.Adam semantics, L2 weight decay folded into the gradient) over the flat parameter /
-    gradient buffers; optionally refreshes the bf16 weight shadow and zeroes the gradient in the same pass."""
+    gradient buffers; optionally refreshes the bf16 weight shadow and zeroes the gradient in the same pass.
+    hyper_dev: optional fp32 CUDA tensor {lr, update count t, -} read on the device instead of lr / step."""
     _req_cuda(p, g, m, v)
     n = p.numel()
     assert g.numel() == n and m.numel() == n and v.numel() == n and (shadow is None or shadow.numel() == n)
+    assert hyper_dev is None or (hyper_dev.dtype == torch.float32 and hyper_dev.numel() == 3 and hyper_dev.is_cuda)
     check(_lib.load().demo_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(shadow), n, float(lr), float(beta1),
-                                     float(beta2), float(eps), float(weight_decay), int(step), int(zero_grad), _stream()), "demo_adam_step")
+                                     float(beta2), float(eps), float(weight_decay), int(step), int(zero_grad), _ptr(hyper_dev), _stream()),
+          "demo_adam_step")
 
 
 def batchnorm_fwd(x: Tensor, w: Tensor, b: Tensor, running_mean: Tensor, running_var: Tensor, training: bool, momentum: float,
@@ -335,8 +338,9 @@ def get_token0(tokens: Tensor, out: Tensor, out_off: int, out_ld: int, Bn: int, 
 
 
 def hdm_softmax_pool(S: Tensor, tokens: Tensor, Bs: int, L: int, Cd: int, Hh: int, ldS: int, p_drop: float = 0.0, seed: int = 0,
-                     save_probs: bool = False, save_probs_post: bool = False):
-    """-> pooled (Bs,7,Hh,C), psum (Bs,7,Hh), probs (softmax BEFORE dropout) [, probs_post (after dropout)]"""
+                     save_probs: bool = False, save_probs_post: bool = False, seed_dev: Optional[Tensor] = None):
+    """-> pooled (Bs,7,Hh,C), psum (Bs,7,Hh), probs (softmax BEFORE dropout) [, probs_post (after dropout)]
+    seed_dev: optional 1-element int64 CUDA tensor added to `seed` on the device (graph-captured training steps)."""
     _req_cuda(S, tokens)
     assert S.dtype == torch.float32 and S.shape == (3 * Bs * L, ldS) and S.is_contiguous() and ldS >= 7 * Hh
     assert tokens.is_contiguous() and tokens.numel() == 3 * Bs * L * Cd
@@ -345,20 +349,22 @@ def hdm_softmax_pool(S: Tensor, tokens: Tensor, Bs: int, L: int, Cd: int, Hh: in
     probs = torch.empty(Bs, 7, Hh, 3 * L, device=S.device, dtype=torch.float32) if save_probs else None
     post = torch.empty(Bs, 7, Hh, 3 * L, device=S.device, dtype=torch.float32) if save_probs_post else None
     check(_lib.load().demo_hdm_softmax_pool(S.data_ptr(), ldS, tokens.data_ptr(), dt_code(tokens.dtype), pooled.data_ptr(), psum.data_ptr(),
-                                            _ptr(probs), _ptr(post), Bs, L, Cd, Hh, float(p_drop), int(seed) & (2 ** 64 - 1), _stream()),
-          "demo_hdm_softmax_pool")
+                                            _ptr(probs), _ptr(post), Bs, L, Cd, Hh, float(p_drop), int(seed) & (2 ** 64 - 1), _ptr(seed_dev),
+                                            _stream()), "demo_hdm_softmax_pool")
     return (pooled, psum, probs, post) if save_probs_post else (pooled, psum, probs)
 
 
 def hdm_softmax_pool_bwd(dpooled: Tensor, dpsum: Optional[Tensor], probs: Tensor, tokens: Tensor, pooled: Tensor, psum: Tensor,
-                         Bs: int, L: int, Cd: int, Hh: int, ldS: int, p_drop: float = 0.0, seed: int = 0):
+                         Bs: int, L: int, Cd: int, Hh: int, ldS: int, p_drop: float = 0.0, seed: int = 0,
+                         seed_dev: Optional[Tensor] = None):
     """-> dS (3Bs*L, ldS) fp32, dtokens (3Bs*L, C) fp32"""
     _req_cuda(dpooled, probs, tokens, pooled, psum)
     dS = torch.empty(3 * Bs * L, ldS, device=tokens.device, dtype=torch.float32)
     dtok = torch.empty(3 * Bs * L, Cd, device=tokens.device, dtype=torch.float32)
     check(_lib.load().demo_hdm_softmax_pool_bwd(dpooled.data_ptr(), _ptr(dpsum), probs.data_ptr(), tokens.data_ptr(), dt_code(tokens.dtype),
                                                 pooled.data_ptr(), psum.data_ptr(), dS.data_ptr(), ldS, dtok.data_ptr(), Bs, L, Cd, Hh,
-                                                float(p_drop), int(seed) & (2 ** 64 - 1), _stream()), "demo_hdm_softmax_pool_bwd")
+                                                float(p_drop), int(seed) & (2 ** 64 - 1), _ptr(seed_dev), _stream()),
+          "demo_hdm_softmax_pool_bwd")
     return dS, dtok
 
 

@@ -64,7 +64,8 @@ typedef struct demo_gemm_desc {
   void* pre_out;          /* optional: value BEFORE `act` (after alpha, bias), indexed and typed like C; saved for backward */
 } demo_gemm_desc;
 int demo_gemm(const demo_gemm_desc* d, void* stream);
-int demo_gemm_path(const demo_gemm_desc* d); /* 1 = bf16 MFMA kernel, 0 = generic kernel (what demo_gemm would pick) */
+/* what demo_gemm would pick: 0 = generic fp32-FMA kernel, 1 = bf16 MFMA 128x128 kernel, 2 = bf16 MFMA 256x256 ping-pong kernel */
+int demo_gemm_path(const demo_gemm_desc* d);
 int demo_gemm_force_tile(int tile); /* tuning hook: 128 / 256 forces that MFMA tile configuration, 0 = heuristic; returns 0 */
 int demo_gemm_desc_size(void); /* sizeof(demo_gemm_desc): lets a foreign binding verify its struct layout */
 
@@ -145,15 +146,19 @@ int demo_get_token0(const void* tokens, int32_t dt, float* out, int64_t out_ld, 
  * scored for every modality; only the attended ones are read), come from demo_gemm against the folded keys.  This kernel: for sample b, branch br (0..6 = r,n,t,rn,rt,nt,rnt)
  * and head h: softmax over the concatenated streams of that branch, optional dropout (seed/offset
  * counter RNG, p_drop), pooled[b,br,h,:] = sum_l p_l * tokens_l  -> fp32 (Bs,7,Hh,C);
- * psum[b,br,h] = sum_l p_l (== 1 without dropout); probs (optional) saved for backward. */
+ * psum[b,br,h] = sum_l p_l (== 1 without dropout); probs (optional) saved for backward.
+ * seed_dev (optional, device memory) is added to seed on the device: a training step captured into a hipGraph replays
+ * with the launch arguments frozen, so whatever must change between steps has to live in device memory. */
 int demo_hdm_softmax_pool(const float* S, int64_t ldS, const void* tokens, int32_t dt, float* pooled, float* psum, float* probs,
-                          float* probs_post, int32_t Bs, int32_t L, int32_t C, int32_t Hh, float p_drop, uint64_t seed, void* stream);
+                          float* probs_post, int32_t Bs, int32_t L, int32_t C, int32_t Hh, float p_drop, uint64_t seed,
+                          const uint64_t* seed_dev, void* stream);
 /* Backward of the above.  probs = the forward's softmax BEFORE dropout (Bs,7,Hh,3L); the dropout mask is regenerated
  * from (seed, p_drop).  dS (3*Bs*L, ldS) fp32 is fully written (zeros in the columns of branches that do not attend a
  * row's modality); dtokens (3*Bs*L, C) fp32 is fully written (row 0 of every image = gradient of the PIFE global). */
 int demo_hdm_softmax_pool_bwd(const float* dpooled, const float* dpsum, const float* probs, const void* tokens, int32_t dt,
                               const float* pooled, const float* psum, float* dS, int64_t ldS, float* dtokens, int32_t Bs,
-                              int32_t L, int32_t C, int32_t Hh, float p_drop, uint64_t seed, void* stream);
+                              int32_t L, int32_t C, int32_t Hh, float p_drop, uint64_t seed, const uint64_t* seed_dev,
+                              void* stream);
 /* value-projection bias under dropout, backward: dbias[br*stride + c] += sum_b dy*psum ; dpsum[b,br,h] += sum_c dy*bias */
 int demo_hdm_vbias_bwd(const float* dy, const float* bias, int64_t bias_stride, const float* psum, float* dbias, float* dpsum,
                        int32_t Bs, int32_t C, int32_t Hh, void* stream);
@@ -193,9 +198,11 @@ int demo_batchnorm_bwd(const float* dy, const float* x, const float* w, const fl
                        int32_t gsz, int32_t n_inner, int32_t n_outer, int64_t pstride, const float* gate, float* dgate, void* stream);
 /* Fused flat Adam step over the flat fp32 parameter buffer (solver/make_optimizer.py: torch.optim.Adam with L2 weight
  * decay; all parameter groups of the reference share lr and decay): updates p, m, v, optionally writes the bf16 weight
- * shadow and zeroes g.  step >= 1 is the 1-based update count used for bias correction. */
+ * shadow and zeroes g.  step >= 1 is the 1-based update count used for bias correction.  hyper_dev (optional, device
+ * memory, floats {lr, update count t}) overrides lr and step: the form a captured (hipGraph) training step uses -- the
+ * launch arguments of a replay are frozen, so the count is advanced by a captured device op and lr by a stream-ordered fill. */
 int demo_adam_step(float* p, float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1, float beta2,
-                   float eps, float weight_decay, int32_t step, int32_t zero_grad, void* stream);
+                   float eps, float weight_decay, int32_t step, int32_t zero_grad, const float* hyper_dev, void* stream);
 /* out[b, 0:C] += dtokens[b, 0, :]   (row-0 gradient of a token stream -> gradient of the global feature) */
 int demo_token0_grad(const float* dtokens, float* out, int64_t out_ld, int32_t Bn, int32_t L, int32_t C, void* stream);
 /* final trunk-output gradient (dtype dt): row 0 = dcls[b] (+ dtok row 0 if keep_row0); row l>=1 = dtok[b,l] + dmean[b]/(L-1);

@@ -130,3 +130,29 @@ def test_full_size_train_step_fp32_grads():
     for n in names:
         e = rel_err(pd[n].grad.detach().cpu(), grads_ref[n])
         assert e < 5e-3, (n, e)
+
+
+def test_graph_replay_matches_eager_steps():
+    """TrainStep(graph=True): two eager steps, capture, replays -- the parameters after 5 steps equal those of 5 eager
+    steps (dropout off: the two modes draw their masks from different seed sources), Adam's device-side count advances."""
+    cfg = small_cfg("clip", head=4, direct=1)
+    x, cam = synth_batch(8, 64, 32, 3)
+    xd = {k: v.to(DEV) for k, v in x.items()}
+    camd = cam.to(DEV)
+    target = torch.tensor([0, 0, 1, 1, 2, 2, 3, 3], device=DEV)
+    flats = []
+    for graph in (False, True):
+        m, _ = build(cfg, 11, 3, torch.float32)
+        ts = TrainStep(m, cfg, 1, lr=1e-3, graph=graph)
+        losses = [ts.step(xd, target, camd).detach().clone() for _ in range(5)]
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(v).item() for v in losses)
+        if graph:
+            assert ts._graph is not None and ts.hyper[1].item() == 5.0
+            assert m.seed_dev.item() != 0
+        flats.append(m.ptab.flat.detach().cpu().clone())
+    # Adam moves every element by ~lr per step whatever the gradient's size, so elements whose gradient is rounding noise
+    # (fp32 atomics order) may differ by a few lr; everything else must agree closely
+    diff = (flats[1] - flats[0]).abs()
+    assert diff.max().item() < 5 * 1e-3
+    assert (diff > 1e-5).float().mean().item() < 1e-3
