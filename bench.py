@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+B_TRAFFIC_VALID = [False]        # the committed PMC traffic figures describe the default workload only (train step, B=128)
 
 
 def parse():
@@ -71,7 +72,12 @@ def gemm_roofline(model, step_fn):
                 e0.record()
                 rc = orig(dref, stream)
                 e1.record()
-                recs[path].append((e0, e1, 2.0 * d.M * d.N * d.K * d.batch1 * d.batch2))
+                nb = d.batch1 * d.batch2
+                szc = 4 if d.dtC == _lib.F32 else 2
+                nbytes = nb * (2 * d.M * d.K + 2 * d.N * d.K + d.M * d.N * szc * (2 if d.pre_out else 1)
+                               + (d.M * d.N * 4 if d.residual else 0) + (d.M * d.N * 4 if d.accumulate else 0)
+                               + (d.M * d.N * (4 if d.dtPre == _lib.F32 else 2) if d.act_grad_pre else 0))
+                recs[path].append((e0, e1, 2.0 * d.M * d.N * d.K * nb, nbytes))
                 return rc
             return orig(dref, stream)
 
@@ -85,19 +91,32 @@ def gemm_roofline(model, step_fn):
     stats = {}
     for path, rs in recs.items():
         if rs:
-            ms = sum(a.elapsed_time(b) for a, b, _ in rs)
-            fl = sum(f for _, _, f in rs)
+            ms = sum(a.elapsed_time(b) for a, b, _, _ in rs)
+            fl = sum(f for _, _, f, _ in rs)
             stats[path] = {"kernel": names[path], "launches_per_step": len(rs), "avg_launch_us": round(ms * 1e3 / len(rs), 1),
                            "ms_per_step": round(ms, 3), "algorithmic_gflop_per_step": round(fl / 1e9, 1),
-                           "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 1)}
+                           "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 1),
+                           "algorithmic_mb_per_launch": round(sum(b for _, _, _, b in rs) / len(rs) / 1e6, 1)}
     if not stats:
         return None
     dom = max(stats, key=lambda k: stats[k]["ms_per_step"])
     s = stats[dom]
+    # HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE doubled for gfx950 + WRITE_SIZE, collected
+    # with rocprofv3 in separate runs of this same command and committed under profiles/): not measurable in-process
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")) as f:
+            t = json.load(f)["kernels"].get(s["kernel"])
+        if t and B_TRAFFIC_VALID[0]:
+            traffic = {"hbm_mb_per_launch": t["hbm_mb_per_launch"], "algorithmic_mb_per_launch": s["algorithmic_mb_per_launch"],
+                       "source": "profiles/r01_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, B=128 train step)"}
+    except (OSError, ValueError, KeyError):
+        pass
     out = {"bound": "mfma", "kernel": s["kernel"], "achieved": s["achieved_tflops"], "peak": MFMA_BF16_PEAK_TFLOPS,
-           "unit": "TFLOP/s", "frac": round(s["achieved_tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+           "unit": "TFLOP/s", "frac": round(s["achieved_tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
            "launches_per_step": s["launches_per_step"], "avg_launch_us": s["avg_launch_us"],
-           "gemm_ms_per_step": s["ms_per_step"], "algorithmic_gflop_per_step": s["algorithmic_gflop_per_step"]}
+           "gemm_ms_per_step": s["ms_per_step"], "algorithmic_gflop_per_step": s["algorithmic_gflop_per_step"],
+           "algorithmic_mb_per_launch": s["algorithmic_mb_per_launch"]}
     other = [v for k, v in stats.items() if k != dom]
     if other:
         out["other_mfma_nt_kernel"] = other[0]
@@ -152,6 +171,7 @@ def main():
     dev = torch.device("cuda", local)
     mode = a.mode if a.mode != "auto" else ("train" if have_backward() else "fwd")
     B = a.batch or (128 if mode == "train" else 64)
+    B_TRAFFIC_VALID[0] = mode == "train" and B == 128 and a.dtype == "bf16"
 
     from demo2_amd.modeling import make_model
     from oracle import demo_oracle as O      # only for the seeded weight factory + cpu_baseline (checker side)

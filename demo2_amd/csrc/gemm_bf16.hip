@@ -36,6 +36,7 @@ struct FArgs {
   int dtC, act, dtPre, act_grad_kind, accumulate;
   float alpha;
   int ntm, ntn;
+  int group_m;                 // 256^2 kernel: row panels per tile-order group
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -523,10 +524,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
   const int tid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-  const int per_group = GROUP_M * p.ntn;
+  // group of row panels walked against all weight panels: sized so that the ~32 workgroups an XCD runs at a time cover ALL
+  // ntn tiles of each of their row panels -- the cold operand (activations, 76..304 MB) is then fetched once, and it is the
+  // hot one (the weight matrix, <= 5 MB, L2 / Infinity-Cache resident) that gets re-read
+  const int group_m = p.group_m;
+  const int per_group = group_m * p.ntn;
   const int grp = tid / per_group, in_grp = tid - grp * per_group;
-  const int gm0 = grp * GROUP_M;
-  const int gsz = (p.ntm - gm0) < GROUP_M ? (p.ntm - gm0) : GROUP_M;
+  const int gm0 = grp * group_m;
+  const int gsz = (p.ntm - gm0) < group_m ? (p.ntm - gm0) : group_m;
   const int m0 = (gm0 + in_grp % gsz) * BM, n0 = (in_grp / gsz) * BN;
   const int z = blockIdx.y;
   const bf16_t* A = p.A + z * p.sA;
@@ -736,6 +741,7 @@ int demo_gemm_bf16(const demo_gemm_desc& d, hipStream_t s) {
     case 2566:
       p.ntm = (int)cdiv64(d.M, 256);
       p.ntn = d.N / 256;
+      p.group_m = 32 / p.ntn < 1 ? 1 : (32 / p.ntn > 8 ? 8 : 32 / p.ntn);      // (2..8 measured within 1 % of each other)
       hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel, dim3((unsigned)(p.ntm * p.ntn), (unsigned)nb), dim3(512), 0, s, p);
       break;
     case 1292: LAUNCH_RS(128, 128, 2, 2); break;
