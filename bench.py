@@ -192,6 +192,10 @@ def main():
         # step are dispatch latency between dependent kernels, not host launch cost -- so eager launches are the default.
         stepper = TrainStep(model, cfg, world, graph=(world == 1 and a.graph))
         model.train()
+        if world > 1:                          # DDP's start-up parameter broadcast (ranks are seeded alike, so a no-op in value)
+            from demo2_amd.dist import broadcast_parameters
+            broadcast_parameters(model)
+            model.refresh_shadow()
 
         def step():
             stepper.step(x, target, cam)
