@@ -76,6 +76,8 @@ PROTOTYPES = {
     "demo_tokens_grad": [_P, _P, _L, _P, _L, _I, _P, _I, _I, _I, _I, _P],
     "demo_hdm_vbias": [_P, _P, _L, _P, _I, _I, _I, _P],
     "demo_atmoe_gate_softmax": [_P, _P, _P, _I, _I, _I, _P],
+    "demo_xent_label_smooth": [_P, _L, _P, _I, _I, _F, _F, _P, _P, _L, _P],
+    "demo_triplet_soft_margin": [_P, _L, _P, _I, _I, _F, _P, _P, _L, _P],
 }
 
 _lib = None

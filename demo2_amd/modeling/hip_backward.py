@@ -376,6 +376,27 @@ def total_loss(outputs, target, loss_fn):
     return loss
 
 
+def fused_loss_and_grads(outputs, target, cfg):
+    """The same total (pairing rule of engine/processor.py:80-97, make_loss 'softmax_triplet' with label smoothing and the
+    soft-margin triplet) through the loss kernels (csrc/loss.hip): returns (loss (1,) fp32, [d loss / d output_i] for the tensor
+    outputs), ready for torch.autograd.backward(outputs, grads) -- the loss itself never enters autograd."""
+    idw, trw = float(cfg.MODEL.ID_LOSS_WEIGHT), float(cfg.MODEL.TRIPLET_LOSS_WEIGHT)
+    n = len(outputs) - (len(outputs) % 2)
+    loss = torch.zeros(1, device=outputs[0].device, dtype=torch.float32)
+    roots, grads = [], []
+    for i in range(0, n, 2):
+        score, feat = outputs[i].detach(), outputs[i + 1].detach()
+        grads.append(ops.xent_label_smooth(score.float().contiguous(), target, loss, 0.1, idw))
+        grads.append(ops.triplet_soft_margin(feat.float().contiguous(), target, loss, trw))
+        roots += [outputs[i], outputs[i + 1]]
+    if len(outputs) % 2 == 1 and torch.is_tensor(outputs[-1]):
+        loss = loss + outputs[-1].detach().float().reshape(1)
+        if outputs[-1].requires_grad:
+            roots.append(outputs[-1])
+            grads.append(torch.ones_like(outputs[-1]))
+    return loss, roots, grads
+
+
 class TrainStep:
     """One optimisation step of the reference's do_train loop (engine/processor.py:57-104) on resident tensors:
     forward, loss, backward (with in-backward RCCL gradient reduction when world > 1), fused flat Adam.
@@ -387,9 +408,10 @@ class TrainStep:
     corrections (3 floats refreshed by an async copy before each replay) and the HDM dropout seed (a device counter that a
     captured kernel advances)."""
 
-    def __init__(self, model, cfg, world=1, lr=None, optimizer=True, graph=False):
+    def __init__(self, model, cfg, world=1, lr=None, optimizer=True, graph=False, fused_loss=True):
         from ..dist import GradSync
         self.model, self.cfg = model, cfg
+        self.fused_loss = bool(fused_loss)     # loss value + output gradients from csrc/loss.hip instead of the torch restatement
         self.loss_fn = make_loss_fn(cfg)
         self.lr = float(cfg.SOLVER.BASE_LR if lr is None else lr)
         self.wd = float(cfg.SOLVER.WEIGHT_DECAY)
@@ -412,8 +434,13 @@ class TrainStep:
     def _run(self, x, target, cam, hyper_dev):
         model = self.model
         out = model(x, label=target, cam_label=cam)
-        loss = total_loss(out, target, self.loss_fn)
-        loss.backward()
+        if self.fused_loss:
+            loss, roots, grads = fused_loss_and_grads(out, target, self.cfg)
+            torch.autograd.backward(roots, grads)
+            loss = loss[0]
+        else:
+            loss = total_loss(out, target, self.loss_fn)
+            loss.backward()
         if self.optimizer:
             if hyper_dev is not None:
                 hyper_dev[1:2].add_(1.0)                               # the device-side update count t

@@ -488,3 +488,29 @@ def atmoe_gate_softmax(q: Tensor, k: Tensor, Bs: int, Cd: int, H: int) -> Tensor
     gates = torch.empty(Bs, H, 7, device=q.device, dtype=torch.float32)
     check(_lib.load().demo_atmoe_gate_softmax(q.data_ptr(), k.data_ptr(), gates.data_ptr(), Bs, Cd, H, _stream()), "demo_atmoe_gate_softmax")
     return gates
+
+
+# ------------------------------------------------------------------------------------------------
+# training losses (value + gradient in one launch)
+# ------------------------------------------------------------------------------------------------
+def xent_label_smooth(logits: Tensor, target: Tensor, loss: Tensor, eps: float = 0.1, weight: float = 1.0, need_grad: bool = True):
+    """loss[0] += weight * CrossEntropyLabelSmooth(logits, target); returns weight * d/dlogits (or None)."""
+    _req_cuda(logits, target, loss)
+    assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1 and target.dtype == torch.int64
+    assert loss.dtype == torch.float32 and loss.numel() >= 1
+    B, K = logits.shape
+    d = torch.empty(B, K, device=logits.device, dtype=torch.float32) if need_grad else None
+    check(_lib.load().demo_xent_label_smooth(logits.data_ptr(), logits.stride(0), target.data_ptr(), B, K, float(eps), float(weight),
+                                             loss.data_ptr(), _ptr(d), K, _stream()), "demo_xent_label_smooth")
+    return d
+
+
+def triplet_soft_margin(feat: Tensor, labels: Tensor, loss: Tensor, weight: float = 1.0, need_grad: bool = True):
+    """loss[0] += weight * TripletLoss()(feat, labels) (batch-hard, soft margin); returns weight * d/dfeat (or None)."""
+    _req_cuda(feat, labels, loss)
+    assert feat.dtype == torch.float32 and feat.dim() == 2 and feat.stride(1) == 1 and labels.dtype == torch.int64
+    B, D = feat.shape
+    d = torch.empty(B, D, device=feat.device, dtype=torch.float32) if need_grad else None
+    check(_lib.load().demo_triplet_soft_margin(feat.data_ptr(), feat.stride(0), labels.data_ptr(), B, D, float(weight), loss.data_ptr(),
+                                               _ptr(d), D, _stream()), "demo_triplet_soft_margin")
+    return d

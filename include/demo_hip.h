@@ -210,6 +210,18 @@ int demo_token0_grad(const float* dtokens, float* out, int64_t out_ld, int32_t B
 int demo_tokens_grad(const float* dtok, const float* dcls, int64_t cls_ld, const float* dmean, int64_t mean_ld, int32_t keep_row0,
                      void* out, int32_t dt, int32_t Bn, int32_t L, int32_t C, void* stream);
 
+/* ---- training losses: value and gradient in one launch -----------------------------------------
+ * CrossEntropyLabelSmooth (layers/softmax_loss.py:23-34): *loss += weight * mean_b sum_k -t_bk log softmax(logits_b)_k with
+ * t = (1-eps) onehot(target) + eps/K;  dlogits (optional, (B, ldd)) = weight * d/dlogits.  loss is a device scalar the
+ * caller zeroes once per step. */
+int demo_xent_label_smooth(const float* logits, int64_t ld, const int64_t* target, int32_t B, int32_t K, float eps, float weight,
+                           float* loss, float* dlogits, int64_t ldd, void* stream);
+/* TripletLoss() without margin (layers/triplet_loss.py:16-31,51-104,121-135): euclidean distances as the reference forms them
+ * (sqrt(clamp(|a|^2+|b|^2-2ab, 1e-12))), batch-hard mining (hardest positive incl. self, hardest negative), SoftMarginLoss:
+ * *loss += weight * mean_i softplus(d_ap - d_an);  dfeat (optional, (B, ldd), OVERWRITTEN) = weight * d/dfeat. */
+int demo_triplet_soft_margin(const float* feat, int64_t ld, const int64_t* labels, int32_t B, int32_t D, float weight, float* loss,
+                             float* dfeat, int64_t ldd, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
