@@ -514,3 +514,47 @@ def triplet_soft_margin(feat: Tensor, labels: Tensor, loss: Tensor, weight: floa
     check(_lib.load().demo_triplet_soft_margin(feat.data_ptr(), feat.stride(0), labels.data_ptr(), B, D, float(weight), loss.data_ptr(),
                                                _ptr(d), D, _stream()), "demo_triplet_soft_margin")
     return d
+
+
+# ------------------------------------------------------------------------------------------------
+# retrieval evaluator
+# ------------------------------------------------------------------------------------------------
+def l2_normalize_rows(x: Tensor, eps: float = 1e-12) -> Tensor:
+    """In place: x[i] /= max(||x[i]||_2, eps)  (torch.nn.functional.normalize(dim=1))."""
+    _req_cuda(x)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    check(_lib.load().demo_l2_normalize_rows(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], float(eps), _stream()), "demo_l2_normalize_rows")
+    return x
+
+
+def row_sqnorm(x: Tensor) -> Tensor:
+    _req_cuda(x)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    out = torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
+    check(_lib.load().demo_row_sqnorm(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], out.data_ptr(), _stream()), "demo_row_sqnorm")
+    return out
+
+
+def add_outer_sum(dist: Tensor, a: Tensor, b: Tensor) -> Tensor:
+    """In place: dist[i, j] = (a[i] + b[j]) + dist[i, j]."""
+    _req_cuda(dist, a, b)
+    nq, ng = dist.shape
+    assert dist.dtype == torch.float32 and dist.stride(1) == 1 and a.numel() == nq and b.numel() == ng
+    check(_lib.load().demo_add_outer_sum(dist.data_ptr(), dist.stride(0), a.data_ptr(), b.data_ptr(), nq, ng, _stream()), "demo_add_outer_sum")
+    return dist
+
+
+def rank_eval(dist: Tensor, q_pids: Tensor, g_pids: Tensor, q_keys: Tensor, g_keys: Tensor, want_order: bool = False):
+    """-> (ap (nq,) float64 or -1, first_hit (nq,) int32 or -1 [, order (nq, ng) int32]); see demo_rank_eval in the header."""
+    _req_cuda(dist, q_pids, g_pids, q_keys, g_keys)
+    nq, ng = dist.shape
+    assert dist.dtype == torch.float32 and dist.stride(1) == 1
+    for t_, n_ in ((q_pids, nq), (g_pids, ng), (q_keys, nq), (g_keys, ng)):
+        assert t_.dtype == torch.int64 and t_.numel() == n_ and t_.is_contiguous()
+    ap = torch.empty(nq, device=dist.device, dtype=torch.float64)
+    first = torch.empty(nq, device=dist.device, dtype=torch.int32)
+    order = torch.empty(nq, ng, device=dist.device, dtype=torch.int32) if want_order else None
+    check(_lib.load().demo_rank_eval(dist.data_ptr(), dist.stride(0), q_pids.data_ptr(), g_pids.data_ptr(), q_keys.data_ptr(),
+                                     g_keys.data_ptr(), nq, ng, ap.data_ptr(), first.data_ptr(), None, _ptr(order), _stream()),
+          "demo_rank_eval")
+    return (ap, first, order) if want_order else (ap, first)

@@ -222,6 +222,22 @@ int demo_xent_label_smooth(const float* logits, int64_t ld, const int64_t* targe
 int demo_triplet_soft_margin(const float* feat, int64_t ld, const int64_t* labels, int32_t B, int32_t D, float weight, float* loss,
                              float* dfeat, int64_t ldd, void* stream);
 
+/* ---- retrieval evaluator (utils/metrics.py) ---------------------------------------------------------
+ * R1_mAP_eval.compute (:341-369): F.normalize -> euclidean_distance (:395-401) -> eval_func (:110-169); R1_mAP (:172-218) with
+ * eval_func_msrv (:12-107) differs only in the removal key (scene id instead of camera id). */
+int demo_l2_normalize_rows(float* x, int64_t ld, int32_t N, int32_t D, float eps, void* stream);      /* x /= max(||x||_2, eps) */
+int demo_row_sqnorm(const float* x, int64_t ld, int32_t N, int32_t D, float* out, void* stream);       /* out[i] = sum_d x[i,d]^2 */
+/* dist[i,j] = (a[i] + b[j]) + dist[i,j]: completes |q|^2 + |g|^2 - 2 q.g^T around a demo_gemm with alpha = -2 */
+int demo_add_outer_sum(float* dist, int64_t ld, const float* a, const float* b, int32_t nq, int32_t ng, void* stream);
+/* per query i: sort the gallery by dist[i,:] (ties by gallery index), drop items with g_pids == q_pids[i] AND g_keys ==
+ * q_keys[i] (keys = camera ids: eval_func; scene ids: eval_func_msrv), then ap[i] = average precision over the kept items
+ * (float64; -1 if the identity does not occur), first_hit[i] = 0-based kept rank of the first match (-1 likewise),
+ * num_rel[i] (optional) = number of kept matches, order_out (optional, (nq, ng) int32) = the sorted gallery indices.
+ * ng <= 16384 (one workgroup sorts a row in LDS). */
+int demo_rank_eval(const float* dist, int64_t ld, const int64_t* q_pids, const int64_t* g_pids, const int64_t* q_keys,
+                   const int64_t* g_keys, int32_t nq, int32_t ng, double* ap, int32_t* first_hit, int32_t* num_rel,
+                   int32_t* order_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
