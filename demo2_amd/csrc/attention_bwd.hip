@@ -220,10 +220,12 @@ __global__ __launch_bounds__(256, NT <= 9 ? 2 : 1) void attn_bwd_bf16_kernel(con
     }
   }
 
-  // ================= pass B: this wave's query tiles (wave, wave+4, wave+8 < NT); all key pairs =====================
+  // ================= pass B: this wave's query tiles; all key pairs ================================================
+  // tiles are dealt in the opposite wave order to pass A (3 - wave, 7 - wave, 11 - wave): with NT = 9 the ninth tile goes
+  // to wave 0 in pass A and to wave 3 here, so no wave carries 3 + 3 tiles (no barrier separates the passes)
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    const int qtile = wave + 4 * a;
+    const int qtile = (3 - wave) + 4 * a;
     if (qtile < NT && qtile * 16 < L) {                      // wave-uniform
       const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(Qs + qtile * 2048 + fo0);
       const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(Qs + qtile * 2048 + fo1);

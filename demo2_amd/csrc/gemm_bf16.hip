@@ -184,9 +184,22 @@ __device__ __forceinline__ void epi8_finish(const FArgs& p, const float4 bz0, co
     *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + ci) = f32x8_to_bf16(v);
   }
 }
+// The act'(pre) source (bf16) of ALL of a thread's rows can be requested before the tile is even staged through LDS (4
+// registers per row): its HBM latency then hides under the staging instead of being paid once per row group.
+template <int NIT, int RSTEP>
+__device__ __forceinline__ bool epi_issue_pre(const FArgs& p, int r0, int mrow0, int n, int64_t coff, uint4 (&raw)[NIT]) {
+  if (!(p.pre && p.dtPre == DEMO_BF16)) return false;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    int m = mrow0 + r0 + it * RSTEP;
+    m = m < p.M ? m : p.M - 1;
+    raw[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.pre) + coff + (int64_t)m * p.ldc + n);
+  }
+  return true;
+}
 template <int NIT, int RSTEP, int BN_, int G, int ACT, int GK>
 __device__ __forceinline__ void epi_rows_k(const FArgs& p, const float* __restrict__ ct, int r0, int mrow0, int n, int c, const float4 bz0,
-                                           const float4 bz1, int64_t coff) {
+                                           const float4 bz1, int64_t coff, const uint4 (&epre)[NIT], bool have_epre) {
   const bool has_pre = GK >= 0 ? GK != DEMO_ACT_NONE : p.pre != nullptr;
   static_assert(NIT % G == 0, "rows are finished G at a time");
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -202,7 +215,10 @@ __device__ __forceinline__ void epi_rows_k(const FArgs& p, const float* __restri
       x[u].pre0 = x[u].pre1 = x[u].res0 = x[u].res1 = x[u].old0 = x[u].old1 = z4;
     }
     if (has_pre) {
-      if (p.dtPre == DEMO_BF16) {
+      if (have_epre) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) bf16x8_to_f32(epre[g0 + u], x[u].pre0, x[u].pre1);
+      } else if (p.dtPre == DEMO_BF16) {
         uint4 raw[G];
 #pragma unroll
         for (int u = 0; u < G; ++u) raw[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.pre) + ci[u]);
@@ -244,20 +260,20 @@ __device__ __forceinline__ void epi_rows_k(const FArgs& p, const float* __restri
 // one compact copy per (activation, activation-gradient) pair the path uses; anything else takes the run-time form
 template <int NIT, int RSTEP, int BN_, int G>
 __device__ __forceinline__ void epi_rows(const FArgs& p, const float* __restrict__ ct, int r0, int mrow0, int n, int c, const float4 bz0,
-                                         const float4 bz1, int64_t coff) {
+                                         const float4 bz1, int64_t coff, const uint4 (&epre)[NIT], bool have_epre) {
   const int gk = p.pre ? p.act_grad_kind : DEMO_ACT_NONE;
   if (p.act == DEMO_ACT_NONE && gk == DEMO_ACT_NONE)
-    epi_rows_k<NIT, RSTEP, BN_, G, DEMO_ACT_NONE, DEMO_ACT_NONE>(p, ct, r0, mrow0, n, c, bz0, bz1, coff);
+    epi_rows_k<NIT, RSTEP, BN_, G, DEMO_ACT_NONE, DEMO_ACT_NONE>(p, ct, r0, mrow0, n, c, bz0, bz1, coff, epre, have_epre);
   else if (p.act == DEMO_ACT_QUICKGELU && gk == DEMO_ACT_NONE)
-    epi_rows_k<NIT, RSTEP, BN_, G, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE>(p, ct, r0, mrow0, n, c, bz0, bz1, coff);
+    epi_rows_k<NIT, RSTEP, BN_, G, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE>(p, ct, r0, mrow0, n, c, bz0, bz1, coff, epre, have_epre);
   else if (p.act == DEMO_ACT_NONE && gk == DEMO_ACT_QUICKGELU)
-    epi_rows_k<NIT, RSTEP, BN_, G, DEMO_ACT_NONE, DEMO_ACT_QUICKGELU>(p, ct, r0, mrow0, n, c, bz0, bz1, coff);
+    epi_rows_k<NIT, RSTEP, BN_, G, DEMO_ACT_NONE, DEMO_ACT_QUICKGELU>(p, ct, r0, mrow0, n, c, bz0, bz1, coff, epre, have_epre);
   else if (p.act == DEMO_ACT_GELU && gk == DEMO_ACT_NONE)
-    epi_rows_k<NIT, RSTEP, BN_, G, DEMO_ACT_GELU, DEMO_ACT_NONE>(p, ct, r0, mrow0, n, c, bz0, bz1, coff);
+    epi_rows_k<NIT, RSTEP, BN_, G, DEMO_ACT_GELU, DEMO_ACT_NONE>(p, ct, r0, mrow0, n, c, bz0, bz1, coff, epre, have_epre);
   else if (p.act == DEMO_ACT_NONE && gk == DEMO_ACT_GELU)
-    epi_rows_k<NIT, RSTEP, BN_, G, DEMO_ACT_NONE, DEMO_ACT_GELU>(p, ct, r0, mrow0, n, c, bz0, bz1, coff);
+    epi_rows_k<NIT, RSTEP, BN_, G, DEMO_ACT_NONE, DEMO_ACT_GELU>(p, ct, r0, mrow0, n, c, bz0, bz1, coff, epre, have_epre);
   else
-    epi_rows_k<NIT, RSTEP, BN_, G, -1, -1>(p, ct, r0, mrow0, n, c, bz0, bz1, coff);
+    epi_rows_k<NIT, RSTEP, BN_, G, -1, -1>(p, ct, r0, mrow0, n, c, bz0, bz1, coff, epre, have_epre);
 }
 
 __device__ __forceinline__ unsigned lds_off(const char* p) {
@@ -438,6 +454,18 @@ void gemm_bf16_nt_kernel(const FArgs p) {
     // Stage the fp32 tile through LDS (the K-loop buffers are free now) and write whole rows: every wave instruction
     // then covers 1-2 full tile rows with 16-B accesses per lane for bias / act'(pre) / residual / C.  The direct form
     // (16 narrow 8-B stores per lane to 16 different rows) is store-ISSUE bound: ~4 us per 128^2 tile (guide, T21).
+    constexpr int CPR = BN / 8;                           // 8-float chunks per row
+    constexpr int NIT = (BM * CPR) / (NW * 64), RSTEP = NW * 64 / CPR;
+    static_assert((NW * 64) % CPR == 0, "a thread must own the same column chunk in every pass");
+    const int c = threadIdx.x % CPR;
+    // requested before the staging: bias for this thread's columns, the act'(pre) source for all of its rows
+    float4 bz0 = make_float4(0.f, 0.f, 0.f, 0.f), bz1 = bz0;
+    if (bias) {
+      bz0 = *reinterpret_cast<const float4*>(bias + n0 + c * 8);
+      bz1 = *reinterpret_cast<const float4*>(bias + n0 + c * 8 + 4);
+    }
+    uint4 epre[NIT];
+    const bool have_epre = epi_issue_pre<NIT, RSTEP>(p, threadIdx.x / CPR, m0, n0 + c * 8, coff, epre);
     __syncthreads();                                      // all waves are done reading the last K-tile
     float* ct = reinterpret_cast<float*>(smem);
     const int g4 = lane >> 4;
@@ -452,15 +480,7 @@ void gemm_bf16_nt_kernel(const FArgs p) {
       }
     }
     __syncthreads();
-    constexpr int CPR = BN / 8;                           // 8-float chunks per row
-    static_assert((NW * 64) % CPR == 0, "a thread must own the same column chunk in every pass");
-    const int c = threadIdx.x % CPR;
-    float4 bz0 = make_float4(0.f, 0.f, 0.f, 0.f), bz1 = bz0;
-    if (bias) {
-      bz0 = *reinterpret_cast<const float4*>(bias + n0 + c * 8);
-      bz1 = *reinterpret_cast<const float4*>(bias + n0 + c * 8 + 4);
-    }
-    epi_rows<(BM * CPR) / (NW * 64), NW * 64 / CPR, BN, 4>(p, ct, threadIdx.x / CPR, m0, n0 + c * 8, c, bz0, bz1, coff);
+    epi_rows<NIT, RSTEP, BN, 4>(p, ct, threadIdx.x / CPR, m0, n0 + c * 8, c, bz0, bz1, coff, epre, have_epre);
   } else {
     // direct form: lane holds C[m][n .. n+3] for each of its MFMA tiles
     const int ng = (lane >> 4) * 4;
@@ -626,6 +646,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
   }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {            // unrolled: acc must be indexed statically (else it lives in scratch)
+    // (no early request of the act'(pre) source here: with the other half's 128 accumulators still live, its 32 registers
+    // spill -- the dispatcher sends act'(pre) products to the 128^2 kernel, which has them to spare)
+    const uint4 epre[8] = {};
+    const bool have_epre = false;
     __syncthreads();
     if (wr == half) {
 #pragma unroll
@@ -640,7 +664,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
       }
     }
     __syncthreads();
-    epi_rows<8, 16, BN, 2>(p, ct, threadIdx.x >> 5, m0 + half * 128, n0 + c * 8, c, bz0, bz1, coff);   // 128 rows x 32 chunks / 512 threads
+    epi_rows<8, 16, BN, 2>(p, ct, threadIdx.x >> 5, m0 + half * 128, n0 + c * 8, c, bz0, bz1, coff, epre, have_epre);   // 128 rows x 32 chunks
   }
 }
 
@@ -690,7 +714,7 @@ int demo_gemm_bf16_config(const demo_gemm_desc& d) {
     // ~1.4 PF/s marginal against ~1.1 for the 128^2 kernel, outweighs the last partial round); measured crossover on
     // M = 49536: N = 2304 / 3072 always, N = 768 from K = 2048
     cfg = 1282;
-    if (d.N % 256 == 0 && d.M >= 1024) {
+    if (d.N % 256 == 0 && d.M >= 1024 && !d.act_grad_pre) {      // (act'(pre) epilogue: 128^2 378 us vs 256^2 411 us at N=3072, K=768)
       const double rounds = (double)cdiv64(d.M, 256) * (d.N / 256) * nb / 256.0;
       const double eff = rounds / (double)(int64_t)(rounds + 0.999999);
       if (eff >= 0.85 || d.K >= 2048) cfg = 2566;
