@@ -77,7 +77,7 @@ PROTOTYPES = {
     "demo_hdm_vbias": [_P, _P, _L, _P, _I, _I, _I, _P],
     "demo_atmoe_gate_softmax": [_P, _P, _P, _I, _I, _I, _P],
     "demo_xent_label_smooth": [_P, _L, _P, _I, _I, _F, _F, _P, _P, _L, _P],
-    "demo_triplet_soft_margin": [_P, _L, _P, _I, _I, _F, _P, _P, _L, _P],
+    "demo_triplet_soft_margin": [_P, _L, _P, _I, _I, _F, _P, _P, _L, _P, _P],
     "demo_l2_normalize_rows": [_P, _L, _I, _I, _F, _P],
     "demo_row_sqnorm": [_P, _L, _I, _I, _P, _P],
     "demo_add_outer_sum": [_P, _L, _P, _P, _I, _I, _P],

@@ -400,6 +400,8 @@ extern "C" int demo_gemm_tn_bf16(const void* A, const void* B, float* C, int32_t
     const int kstages = (Kr + PBK - 1) / PBK;
     int splitk = tiles >= 256 ? 1 : 256 / tiles;
     if (splitk > kstages / 16) splitk = kstages / 16 > 0 ? kstages / 16 : 1;      // at least 16 stages per workgroup
+    // (capping the slices per tile to cut the fp32-atomic traffic was measured: 42 -> 16 slices on a 512 x 768 output costs
+    // 103 -> 119 us, 28 -> 16 on 768 x 768 costs 117 -> 128 us: filling the CUs wins)
     const int per = (kstages + splitk - 1) / splitk;
     p.kper = per * PBK;
     p.splitk = (kstages + per - 1) / per;

@@ -56,86 +56,57 @@ __global__ __launch_bounds__(256) void xent_label_smooth_kernel(const float* __r
   }
 }
 
-// one workgroup per anchor i.  dist(i,j) = sqrt(max(|f_i|^2 + |f_j|^2 - 2 f_i.f_j, 1e-12)) exactly as the reference forms it;
-// hardest positive = arg max over same-label j (self included, first index on ties), hardest negative = arg min over the rest;
-// loss += w/B * softplus(d_ap - d_an);  with g = w/B * sigmoid(d_ap - d_an):
-//   df_i += g (f_i - f_p)/d_ap - g (f_i - f_n)/d_an ,  df_p -= g (f_i - f_p)/d_ap ,  df_n += g (f_i - f_n)/d_an   (fp32 atomics)
-__global__ __launch_bounds__(256) void triplet_soft_margin_kernel(const float* __restrict__ feat, int64_t ld, const int64_t* __restrict__ labels,
-                                                                  int B, int D, float w, float* __restrict__ loss,
-                                                                  float* __restrict__ dfeat, int64_t ldd) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // f_i [D] | dist2 [B]
-  float* fi = sm;
-  float* d2 = sm + D;
-  __shared__ float s_best[2];
-  __shared__ int s_idx[2];
-  const int i = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* xi = feat + (int64_t)i * ld;
-  for (int d = threadIdx.x; d < D; d += 256) fi[d] = xi[d];
-  __syncthreads();
-  float sqi = 0.f;
-  for (int d = lane; d < D; d += 64) sqi = fmaf(fi[d], fi[d], sqi);
-  sqi = wave_sum(sqi);
-  for (int j = wave; j < B; j += 4) {
-    const float* xj = feat + (int64_t)j * ld;
-    float dot = 0.f, sqj = 0.f;
-    for (int d = lane; d < D; d += 64) {
-      const float v = xj[d];
-      dot = fmaf(fi[d], v, dot);
-      sqj = fmaf(v, v, sqj);
-    }
-    dot = wave_sum(dot);
-    sqj = wave_sum(sqj);
-    if (lane == 0) d2[j] = fmaxf(sqi + sqj - 2.f * dot, 1e-12f);
-  }
-  __syncthreads();
-  if (wave == 0) {                                          // mining by one wave: (value, index) reductions over B entries
-    const int64_t li = labels[i];
-    float bp = -INFINITY, bn = INFINITY;
-    int ip = -1, in_ = -1;
-    for (int j = lane; j < B; j += 64) {
-      const float v = sqrtf(d2[j]);
-      if (labels[j] == li) {
-        if (v > bp) { bp = v; ip = j; }
-      } else if (v < bn) {
-        bn = v; in_ = j;
-      }
-    }
-    // arg max / arg min across lanes with "first index wins" on equal values
-    for (int o = 32; o > 0; o >>= 1) {
-      const float obp = __shfl_xor(bp, o, 64), obn = __shfl_xor(bn, o, 64);
-      const int oip = __shfl_xor(ip, o, 64), oin = __shfl_xor(in_, o, 64);
-      if (oip >= 0 && (ip < 0 || obp > bp || (obp == bp && oip < ip))) { bp = obp; ip = oip; }
-      if (oin >= 0 && (in_ < 0 || obn < bn || (obn == bn && oin < in_))) { bn = obn; in_ = oin; }
-    }
-    if (lane == 0) {
-      s_best[0] = bp; s_best[1] = bn;
-      s_idx[0] = ip; s_idx[1] = in_;
+// Batch-hard triplet, in three steps that are all tiny:
+//   (1) Gram matrix G = F F^T (B x B, fp32) by the generic GEMM -- the reference forms its distances the same way
+//       (dist^2 = |f_i|^2 + |f_j|^2 - 2 f_i.f_j, clamp 1e-12, sqrt; layers/triplet_loss.py:16-31);
+//   (2) this kernel, one wave per anchor i: hardest positive = arg max over same-label j (self included, first index on
+//       ties), hardest negative = arg min over the rest; loss += w/B * softplus(d_ap - d_an); and the gradient as a sparse
+//       B x B weight matrix Wt with dF = Wt F:  with g = w/B * sigmoid(d_ap - d_an), cp = g/d_ap, cn = g/d_an
+//           row i: Wt[i,i] += cp - cn, Wt[i,p] -= cp, Wt[i,n] += cn;  row p: Wt[p,i] -= cp, Wt[p,p] += cp;
+//           row n: Wt[n,i] += cn, Wt[n,n] -= cn        (fp32 atomics: rows p / n belong to other anchors too)
+//   (3) dF = Wt F by the generic GEMM.
+// (A first version computed the B^2 dot products inside this kernel, one workgroup per anchor: 458 us at D = 3584.)
+__global__ __launch_bounds__(64) void triplet_mine_kernel(const float* __restrict__ G, const int64_t* __restrict__ labels, int B, float w,
+                                                          float* __restrict__ loss, float* __restrict__ Wt) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const int64_t li = labels[i];
+  const float gii = G[(int64_t)i * B + i];
+  float bp = -INFINITY, bn = INFINITY;
+  int ip = -1, in_ = -1;
+  for (int j = lane; j < B; j += 64) {
+    const float d2 = fmaxf(gii + G[(int64_t)j * B + j] - 2.f * G[(int64_t)i * B + j], 1e-12f);
+    const float v = sqrtf(d2);
+    if (labels[j] == li) {
+      if (v > bp) { bp = v; ip = j; }
+    } else if (v < bn) {
+      bn = v; in_ = j;
     }
   }
-  __syncthreads();
-  const float d_ap = s_best[0], d_an = s_best[1];
-  const int p = s_idx[0], n = s_idx[1];
-  if (p < 0 || n < 0) return;                               // no positive / no negative in the batch: contributes nothing
-  const float z = d_ap - d_an;                               // softplus(z), sigmoid(z)
+  for (int o = 32; o > 0; o >>= 1) {                         // arg max / arg min across lanes, first index wins on ties
+    const float obp = __shfl_xor(bp, o, 64), obn = __shfl_xor(bn, o, 64);
+    const int oip = __shfl_xor(ip, o, 64), oin = __shfl_xor(in_, o, 64);
+    if (oip >= 0 && (ip < 0 || obp > bp || (obp == bp && oip < ip))) { bp = obp; ip = oip; }
+    if (oin >= 0 && (in_ < 0 || obn < bn || (obn == bn && oin < in_))) { bn = obn; in_ = oin; }
+  }
+  if (lane != 0 || ip < 0 || in_ < 0) return;                // no positive / no negative in the batch: contributes nothing
+  const float z = bp - bn;
   const float wb = w / (float)B;
-  if (threadIdx.x == 0) atomicAdd(loss, wb * (z > 20.f ? z : log1pf(__expf(z))));
-  if (!dfeat) return;
+  atomicAdd(loss, wb * (z > 20.f ? z : log1pf(__expf(z))));
+  if (!Wt) return;
   const float g = wb / (1.f + __expf(-z));
   // the clamp passes no gradient where it is active (dist^2 == 1e-12: coincident points, e.g. self as hardest positive)
-  const float cp = d2[p] > 1e-12f ? g / d_ap : 0.f;
-  const float cn = d2[n] > 1e-12f ? g / d_an : 0.f;
-  const float* xp = feat + (int64_t)p * ld;
-  const float* xn = feat + (int64_t)n * ld;
-  float* gi = dfeat + (int64_t)i * ldd;
-  float* gp = dfeat + (int64_t)p * ldd;
-  float* gn = dfeat + (int64_t)n * ldd;
-  for (int d = threadIdx.x; d < D; d += 256) {
-    const float a = cp * (fi[d] - xp[d]), c = cn * (fi[d] - xn[d]);
-    atomicAdd(gi + d, a - c);
-    atomicAdd(gp + d, -a);
-    atomicAdd(gn + d, c);
-  }
+  const int p = ip, n = in_;
+  const float d2p = gii + G[(int64_t)p * B + p] - 2.f * G[(int64_t)i * B + p];
+  const float d2n = gii + G[(int64_t)n * B + n] - 2.f * G[(int64_t)i * B + n];
+  const float cp = d2p > 1e-12f ? g / bp : 0.f;
+  const float cn = d2n > 1e-12f ? g / bn : 0.f;
+  atomicAdd(Wt + (int64_t)i * B + i, cp - cn);
+  atomicAdd(Wt + (int64_t)i * B + p, -cp);
+  atomicAdd(Wt + (int64_t)i * B + n, cn);
+  atomicAdd(Wt + (int64_t)p * B + i, -cp);
+  atomicAdd(Wt + (int64_t)p * B + p, cp);
+  atomicAdd(Wt + (int64_t)n * B + i, cn);
+  atomicAdd(Wt + (int64_t)n * B + n, -cn);
 }
 
 }  // namespace
@@ -149,17 +120,37 @@ extern "C" int demo_xent_label_smooth(const float* logits, int64_t ld, const int
   return 0;
 }
 
+extern "C" int demo_gemm(const demo_gemm_desc* d, void* stream);
+
 extern "C" int demo_triplet_soft_margin(const float* feat, int64_t ld, const int64_t* labels, int32_t B, int32_t D, float weight, float* loss,
-                                        float* dfeat, int64_t ldd, void* stream) {
-  DEMO_REQUIRE(feat && labels && loss && B > 0 && D > 0 && ld >= D, "demo_triplet_soft_margin: bad arguments");
-  const size_t shm = sizeof(float) * ((size_t)D + B);
-  DEMO_REQUIRE(shm <= 64 * 1024, "demo_triplet_soft_margin: D=%d B=%d need %zu B of LDS", D, B, shm);
+                                        float* dfeat, int64_t ldd, float* workspace, void* stream) {
+  DEMO_REQUIRE(feat && labels && loss && workspace && B > 0 && D > 0 && ld >= D, "demo_triplet_soft_margin: bad arguments");
   hipStream_t s = (hipStream_t)stream;
+  float* G = workspace;                         // (B, B) Gram matrix
+  float* Wt = workspace + (size_t)B * B;        // (B, B) gradient weights
+  demo_gemm_desc g = {};
+  g.A = feat; g.B = feat; g.C = G;
+  g.M = B; g.N = B; g.K = D;
+  g.a_rs = ld; g.a_cs = 1; g.b_rs = ld; g.b_cs = 1; g.c_rs = B;
+  g.dtA = g.dtB = g.dtC = DEMO_F32;
+  g.act = DEMO_ACT_NONE; g.alpha = 1.f; g.batch1 = g.batch2 = 1;
+  int rc = demo_gemm(&g, stream);
+  if (rc) return rc;
   if (dfeat) {
-    hipError_t e = hipMemset2DAsync(dfeat, (size_t)ldd * sizeof(float), 0, (size_t)D * sizeof(float), (size_t)B, s);
+    hipError_t e = hipMemsetAsync(Wt, 0, sizeof(float) * (size_t)B * B, s);
     if (e != hipSuccess) DEMO_FAIL(-2, "demo_triplet_soft_margin: memset failed: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(triplet_soft_margin_kernel, dim3(B), dim3(256), shm, s, feat, ld, labels, B, D, weight, loss, dfeat, ldd);
+  hipLaunchKernelGGL(triplet_mine_kernel, dim3(B), dim3(64), 0, s, G, labels, B, weight, loss, dfeat ? Wt : nullptr);
   DEMO_LAUNCH_CHECK("demo_triplet_soft_margin");
+  if (dfeat) {                                  // dF[i, d] = sum_j Wt[i, j] F[j, d]
+    demo_gemm_desc h = {};
+    h.A = Wt; h.B = feat; h.C = dfeat;
+    h.M = B; h.N = D; h.K = B;
+    h.a_rs = B; h.a_cs = 1; h.b_rs = 1; h.b_cs = ld; h.c_rs = ldd;
+    h.dtA = h.dtB = h.dtC = DEMO_F32;
+    h.act = DEMO_ACT_NONE; h.alpha = 1.f; h.batch1 = h.batch2 = 1;
+    rc = demo_gemm(&h, stream);
+    if (rc) return rc;
+  }
   return 0;
 }

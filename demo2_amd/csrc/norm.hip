@@ -421,7 +421,7 @@ extern "C" int demo_layernorm_bwd(const void* dy, int32_t dtDy, const float* x, 
                                   float* workspace, int64_t workspace_elems, int32_t M, int32_t D, void* stream) {
   DEMO_REQUIRE(D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "demo_layernorm_bwd: D=%d unsupported", D);
   hipStream_t s = (hipStream_t)stream;
-  const int rows_per_block = 16;      // 4 rows per wave: ~3000 workgroups at 3B*L = 49536 rows keep every CU's memory pipes full
+  const int rows_per_block = M >= 16384 ? 32 : 16;      // ~1500 workgroups at 3B*L = 49536 rows; fewer partial dw/db rows for the reduce kernel
   const int nblk = (int)cdiv64(M, rows_per_block);
   dim3 grid((unsigned)nblk);
   const size_t shm = 2 * (size_t)D * sizeof(float);

@@ -511,8 +511,9 @@ def triplet_soft_margin(feat: Tensor, labels: Tensor, loss: Tensor, weight: floa
     assert feat.dtype == torch.float32 and feat.dim() == 2 and feat.stride(1) == 1 and labels.dtype == torch.int64
     B, D = feat.shape
     d = torch.empty(B, D, device=feat.device, dtype=torch.float32) if need_grad else None
+    ws = torch.empty(2 * B * B, device=feat.device, dtype=torch.float32)        # Gram matrix + gradient weights
     check(_lib.load().demo_triplet_soft_margin(feat.data_ptr(), feat.stride(0), labels.data_ptr(), B, D, float(weight), loss.data_ptr(),
-                                               _ptr(d), D, _stream()), "demo_triplet_soft_margin")
+                                               _ptr(d), D, ws.data_ptr(), _stream()), "demo_triplet_soft_margin")
     return d
 
 

@@ -218,9 +218,11 @@ int demo_xent_label_smooth(const float* logits, int64_t ld, const int64_t* targe
                            float* loss, float* dlogits, int64_t ldd, void* stream);
 /* TripletLoss() without margin (layers/triplet_loss.py:16-31,51-104,121-135): euclidean distances as the reference forms them
  * (sqrt(clamp(|a|^2+|b|^2-2ab, 1e-12))), batch-hard mining (hardest positive incl. self, hardest negative), SoftMarginLoss:
- * *loss += weight * mean_i softplus(d_ap - d_an);  dfeat (optional, (B, ldd), OVERWRITTEN) = weight * d/dfeat. */
+ * *loss += weight * mean_i softplus(d_ap - d_an);  dfeat (optional, (B, ldd), OVERWRITTEN) = weight * d/dfeat.
+ * workspace: 2*B*B floats (Gram matrix F F^T and the sparse gradient weights Wt with dfeat = Wt F; both products run on
+ * demo_gemm's fp32 kernel). */
 int demo_triplet_soft_margin(const float* feat, int64_t ld, const int64_t* labels, int32_t B, int32_t D, float weight, float* loss,
-                             float* dfeat, int64_t ldd, void* stream);
+                             float* dfeat, int64_t ldd, float* workspace, void* stream);
 
 /* ---- retrieval evaluator (utils/metrics.py) ---------------------------------------------------------
  * R1_mAP_eval.compute (:341-369): F.normalize -> euclidean_distance (:395-401) -> eval_func (:110-169); R1_mAP (:172-218) with

@@ -56,7 +56,7 @@ def timeit(fn, reps):
 
 
 M, W = 3 * a.batch * 129, 768
-for name, n, k in [("qkv", 3 * W, W), ("proj", W, W), ("fc1", 4 * W, W), ("fc2", W, 4 * W)]:
+for name, n, k in [("qkv", 3 * W, W), ("proj", W, W), ("fc1", 4 * W, W), ("fc2", W, 4 * W), ("clipproj", 512, W)]:
     dy = torch.randn(M, n, device=dev).bfloat16()
     x = torch.randn(M, k, device=dev).bfloat16()
     g = torch.zeros(n, k, device=dev)
