@@ -238,6 +238,22 @@ __device__ __forceinline__ void pp_stage_op_tail(const bf16_t* __restrict__ G, i
   for (int j = 0; j < 2; ++j) *reinterpret_cast<uint4*>(lds_tile + (j * 8 + wave) * 1024 + lane * 16) = v[j];
 }
 
+// The two transposing reads of one fragment as INLINE ASM, not waited for here.  With the builtin form hipcc sees an LDS load
+// that may alias the LDS-DMA writes (global_load_lds) and puts s_waitcnt vmcnt(0) in front of every group of reads: that
+// drains the three stages kept in flight and the kernel runs at memory-latency speed (measured: 750 TFLOP/s with the
+// builtin).  The caller waits lgkmcnt(0) after the barrier and pins the order with sched_barrier, as in the NT kernel.
+__device__ __forceinline__ void pp_tr_read(s16x4 (&f)[2], unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\t"
+               "ds_read_b64_tr_b16 %1, %2 offset:2048"
+               : "=&v"(f[0]), "=&v"(f[1])
+               : "v"(addr)
+               : "memory");
+}
+__device__ __forceinline__ bf16x8 pp_join(const s16x4 (&f)[2]) { return __builtin_shufflevector(f[0], f[1], 0, 1, 2, 3, 4, 5, 6, 7); }
+__device__ __forceinline__ unsigned pp_lds_off(const char* p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+
 __device__ __forceinline__ bf16x8 pp_tr_frag(const char* base, int off) {
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + off));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + off + 4 * 512));
@@ -268,9 +284,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_pp_kernel(const TArgs p) 
   const int g = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
   const int sw = (q << 1) | ((g & 1) << 3);
   const int lbase = (8 * g + q) * 512 + ((pp & 1) << 3), csub = pp >> 1;
+  // Row tiles are taken in an order rotated by wc: accumulator slot i of a phase holds row tile (i + wc) & 3 of that phase.
+  // The four waves of a half read the same A fragments anyway; with the rotation "the row tile whose bias gradient this
+  // wave sums" is always fragment 0 -- a compile-time register, no per-phase select chain (which cost 12 % with colsum on).
   int aoff[8], boff[4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) aoff[i] = lbase + ((((wr * 8 + i) * 2 + csub) ^ sw) << 4);
+  for (int i = 0; i < 8; ++i) aoff[i] = lbase + ((((wr * 8 + (i & 4) + ((i + wc) & 3)) * 2 + csub) ^ sw) << 4);
 #pragma unroll
   for (int j = 0; j < 4; ++j) boff[j] = POP_BYTES + lbase + ((((wc * 4 + j) * 2 + csub) ^ sw) << 4);
 
@@ -305,17 +324,25 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_pp_kernel(const TArgs p) 
   if (wr == 1) __builtin_amdgcn_s_barrier();        // this half runs one barrier behind from here on
 
   int slot = 0;
+  const unsigned lds_base = pp_lds_off(smem);
   for (int t = 0; t < nk; ++t) {
-    const char* cur = smem + slot * PSTAGE_BYTES;
+    const unsigned cur = lds_base + slot * PSTAGE_BYTES;
     slot = slot + 1 == PSTAGES ? 0 : slot + 1;
+    s16x4 araw[4][2], braw[4][2];
     bf16x8 af[4], bfr[4];
     // ---- phase 1: output rows 0..63 of the wave
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bfr[j] = pp_tr_frag(cur, boff[j]);
+    for (int j = 0; j < 4; ++j) pp_tr_read(braw[j], cur + boff[j]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = pp_tr_frag(cur, aoff[i]);
+    for (int i = 0; i < 4; ++i) pp_tr_read(araw[i], cur + aoff[i]);
     if (t + 3 < nk) stage(t + 3);
     __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = pp_join(braw[j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = pp_join(araw[i]);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -323,29 +350,33 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_pp_kernel(const TArgs p) 
       for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     if constexpr (CS) {
       // bias gradient, branch-free (a wave-uniform `if` around an MFMA makes hipcc copy accumulators): wave wc sums output
-      // row tile wc of this phase, i.e. its A fragment times ones: one extra MFMA per 16
-      const bf16x8 asel = wc == 0 ? af[0] : (wc == 1 ? af[1] : (wc == 2 ? af[2] : af[3]));
-      csum[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asel, ones, csum[0], 0, 0, 0);
+      // row tile wc of this phase = its fragment 0 (rotated order) times ones: one extra MFMA per 16
+      csum[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], ones, csum[0], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     // ---- phase 2: output rows 64..127 of the wave; stage t+1 must have landed before the first barrier
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = pp_tr_frag(cur, aoff[4 + i]);
+    for (int i = 0; i < 4; ++i) pp_tr_read(araw[i], cur + aoff[4 + i]);
     if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = pp_join(araw[i]);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[4 + i][j], 0, 0, 0);
     if constexpr (CS) {
-      const bf16x8 asel = wc == 0 ? af[0] : (wc == 1 ? af[1] : (wc == 2 ? af[2] : af[3]));
-      csum[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asel, ones, csum[1], 0, 0, 0);
+      csum[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], ones, csum[1], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();        // re-join the halves
@@ -367,7 +398,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_pp_kernel(const TArgs p) 
       const int n = n0 + wc * 64 + j * 16 + idx;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wr * 128 + i * 16 + 4 * g + r;
+        const int m = m0 + wr * 128 + ((i & 4) + ((i + wc) & 3)) * 16 + 4 * g + r;      // rotated row-tile order
         float* c = p.C + (int64_t)m * p.ldc + n;
         const float v = acc[i][j][r] * p.alpha;
         if (p.use_atomics) atomicAdd(c, v);
