@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
     for (int kt = 0; kt < 10; ++kt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = exp2f(s[kt][r] * c2 - mc);
+        const float p = __builtin_amdgcn_exp2f(s[kt][r] * c2 - mc);
         s[kt][r] = p;
         sum += p;
       }

@@ -23,6 +23,7 @@
 //
 // generic kernel: fp32 math on the vector ALUs (parity mode and shapes outside the MFMA kernel's contract).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256, NT <= 9 ? 2 : 1) void attn_bwd_bf16_kernel(con
                                                                              const bf16_t* __restrict__ dout,
                                                                              const float* __restrict__ lse,
                                                                              bf16_t* __restrict__ dqkv, int L, int H, float scale) {
-  constexpr int LP = NT * 16, MAT_BYTES = LP * 128, NPAIR = (NT + 1) / 2, NIT = (LP * 8 + 255) / 256;
+  constexpr int LP = NT * 16, MAT_BYTES = LP * 128, NIT = (LP * 8 + 255) / 256;
   __shared__ __attribute__((aligned(1024))) char smem[4 * MAT_BYTES + 2 * LP * 4];
   char* Qs = smem;
   char* Gs = smem + MAT_BYTES;                // dO
@@ -134,8 +135,10 @@ __global__ __launch_bounds__(256, NT <= 9 ? 2 : 1) void attn_bwd_bf16_kernel(con
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) { dVa[a][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dKa[a][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-    for (int qp = 0; qp < NPAIR; ++qp) {
-      const bool t1 = qp * 2 + 1 < NT;                       // second query tile of the pair exists
+    // body of one query pair; T1 = the pair's second tile exists -- a compile-time fact (false only for the last pair of an
+    // odd NT), so the full pairs carry no masking selects at all
+    auto pass_a = [&](int qp, auto t1c) {
+      constexpr bool t1 = decltype(t1c)::value;
       // row fragments of the two query tiles (A operands of S and dP)
       bf16x8 qf[2][2], gf[2][2];
 #pragma unroll
@@ -161,7 +164,9 @@ __global__ __launch_bounds__(256, NT <= 9 ? 2 : 1) void attn_bwd_bf16_kernel(con
       float l2[2][4], dl[2][4];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), d4 = a4;
+        // a tile that does not exist (odd NT, second half of the last pair) gets LSE = +inf: p = exp2(-inf) = 0 and
+        // dS = 0 with no per-element selects
+        float4 a4 = make_float4(INFINITY, INFINITY, INFINITY, INFINITY), d4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (hh == 0 || t1) {
           a4 = *reinterpret_cast<const float4*>(lse2 + (qp * 2 + hh) * 16 + 4 * g);
           d4 = *reinterpret_cast<const float4*>(dlt + (qp * 2 + hh) * 16 + 4 * g);
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(256, NT <= 9 ? 2 : 1) void attn_bwd_bf16_kernel(con
           const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(Ks + kt * 2048 + fo1);
           const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(Vs + kt * 2048 + fo0);
           const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(Vs + kt * 2048 + fo1);
-          bf16x8 pb, db;
+          u32x4 pw, dw;                                      // bf16 pairs, packed two per v_cvt_pk_bf16_f32
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -185,15 +190,16 @@ __global__ __launch_bounds__(256, NT <= 9 ? 2 : 1) void attn_bwd_bf16_kernel(con
             s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[hh][1], kf1, s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[hh][0], vf0, dp, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[hh][1], vf1, dp, 0, 0, 0);
-            const bool tv = hh == 0 || t1;
+            float pv[4], dv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float p = exp2f(s[r] * c2 - l2[hh][r]);
-              const float ds = p * (dp[r] - dl[hh][r]) * scale;
-              pb[hh * 4 + r] = tv ? (short)f2bf(p) : (short)0;
-              db[hh * 4 + r] = tv ? (short)f2bf(ds) : (short)0;
+              pv[r] = __builtin_amdgcn_exp2f(s[r] * c2 - l2[hh][r]);
+              dv[r] = pv[r] * (dp[r] - dl[hh][r]) * scale;
             }
+            pw[hh * 2] = pack_bf16x2(pv[0], pv[1]); pw[hh * 2 + 1] = pack_bf16x2(pv[2], pv[3]);
+            dw[hh * 2] = pack_bf16x2(dv[0], dv[1]); dw[hh * 2 + 1] = pack_bf16x2(dv[2], dv[3]);
           }
+          const bf16x8 pb = __builtin_bit_cast(bf16x8, pw), db = __builtin_bit_cast(bf16x8, dw);
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) {
             dVa[a][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gt[dt], pb, dVa[a][dt], 0, 0, 0);
@@ -201,7 +207,9 @@ __global__ __launch_bounds__(256, NT <= 9 ? 2 : 1) void attn_bwd_bf16_kernel(con
           }
         }
       }
-    }
+    };
+    for (int qp = 0; qp < NT / 2; ++qp) pass_a(qp, std::true_type{});
+    if constexpr (NT & 1) pass_a(NT / 2, std::false_type{});
     // dK^T / dV^T tiles: D[row = d = 4g + reg][col = key = li] -> 4 consecutive d per lane
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -235,9 +243,9 @@ __global__ __launch_bounds__(256, NT <= 9 ? 2 : 1) void attn_bwd_bf16_kernel(con
       f32x4 dq[4];
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      for (int kp = 0; kp < NPAIR; ++kp) {
-        const bool t1 = kp * 2 + 1 < NT;
-        bf16x8 dsb;
+      auto pass_b = [&](int kp, auto t1c) {
+        constexpr bool t1 = decltype(t1c)::value;
+        u32x4 dsw;                   // (a missing key tile needs no masking here: its K^T fragment half below is zero)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           const bool tv = hh == 0 || t1;
@@ -255,19 +263,21 @@ __global__ __launch_bounds__(256, NT <= 9 ? 2 : 1) void attn_bwd_bf16_kernel(con
           s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf1, s, 0, 0, 0);
           dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, gf0, dp, 0, 0, 0);
           dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, gf1, dp, 0, 0, 0);
+          float dv[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = exp2f(s[r] * c2 - l2q);
-            const float ds = p * (dp[r] - dlq) * scale;
-            dsb[hh * 4 + r] = tv ? (short)f2bf(ds) : (short)0;
-          }
+          for (int r = 0; r < 4; ++r) dv[r] = __builtin_amdgcn_exp2f(s[r] * c2 - l2q) * (dp[r] - dlq) * scale;
+          dsw[hh * 2] = pack_bf16x2(dv[0], dv[1]);
+          dsw[hh * 2 + 1] = pack_bf16x2(dv[2], dv[3]);
         }
+        const bf16x8 dsb = __builtin_bit_cast(bf16x8, dsw);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           const bf16x8 ka = tr_frag_opt(Ks + kp * 4096, to[dt], to[dt] + 2048, t1);
           dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, dsb, dq[dt], 0, 0, 0);
         }
-      }
+      };
+      for (int kp = 0; kp < NT / 2; ++kp) pass_b(kp, std::true_type{});
+      if constexpr (NT & 1) pass_b(NT / 2, std::false_type{});
       const int q = qtile * 16 + li;
       if (q < L) {
         bf16_t* row = dqkv + ((int64_t)b * L + q) * ld3 + h * 64 + 4 * g;

@@ -39,6 +39,14 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(bf16_t, h);
 }
 
+// two floats -> one 32-bit word of two bf16 (low half = first): a single v_cvt_pk_bf16_f32, no shift/and/or repacking
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+  const bf2_t v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+
 template <typename T> struct io;
 template <> struct io<float> {
   static __device__ __forceinline__ float ld(const float* p) { return *p; }
