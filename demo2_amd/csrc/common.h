@@ -107,13 +107,14 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // ---- activations ---------------------------------------------------------------------------------
 __device__ __forceinline__ float act_apply(float x, int act) {
-  if (act == DEMO_ACT_QUICKGELU) return x / (1.0f + __expf(-1.702f * x));
+  // (v_rcp_f32 is accurate to 1 ulp; a true division is ~10 more instructions per element of the GEMM epilogue)
+  if (act == DEMO_ACT_QUICKGELU) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
   if (act == DEMO_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
   return x;
 }
 __device__ __forceinline__ float act_grad(float x, int act) {
   if (act == DEMO_ACT_QUICKGELU) {
-    float s = 1.0f / (1.0f + __expf(-1.702f * x));
+    float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
     return s * (1.0f + 1.702f * x * (1.0f - s));
   }
   if (act == DEMO_ACT_GELU) {
