@@ -164,9 +164,17 @@ def main():
     a = parse()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    # rehearsal of the N > 1 control flow on a one-GPU box: DEMO_BENCH_REHEARSAL=1 puts every rank on cuda:0 and reduces
+    # over gloo (functional check only; the numbers mean nothing)
+    rehearsal = os.environ.get("DEMO_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     mode = a.mode if a.mode != "auto" else ("train" if have_backward() else "fwd")
@@ -235,7 +243,13 @@ def main():
     log(f"timed region: {dt:.3f} s for {a.steps} steps")
     roof = cpu = None
     if rank == 0:
-        roof = gemm_roofline(model, eager_step)
+        # the instrumented extra step runs on rank 0 ONLY: it must not issue collectives the other ranks never join
+        saved_sync = getattr(model, "grad_sync", None)
+        model.grad_sync = None
+        try:
+            roof = gemm_roofline(model, eager_step)
+        finally:
+            model.grad_sync = saved_sync
         log("roofline pass done; cpu baseline next")
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(mode, a.cpu_seconds)

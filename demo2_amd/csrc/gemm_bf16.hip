@@ -202,16 +202,23 @@ __device__ __forceinline__ void epi_rows_k(const FArgs& p, const float* __restri
                                            const float4 bz1, int64_t coff, const uint4 (&epre)[NIT], bool have_epre) {
   const bool has_pre = GK >= 0 ? GK != DEMO_ACT_NONE : p.pre != nullptr;
   static_assert(NIT % G == 0, "rows are finished G at a time");
+  static_assert(RSTEP % 8 == 0, "the LDS slot swizzle (row & 7) must be the same for every row of a thread");
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // per-row index arithmetic hoisted: a thread's rows are RSTEP apart, so the swizzled LDS slots are fixed and both the LDS and
+  // the global address advance by constants (the epilogue is VALU-sensitive: ~50 instructions per row before this)
+  const float* ctl = ct + r0 * BN_ + (((2 * c) ^ (r0 & 7)) << 2);
+  const float* cth = ct + r0 * BN_ + (((2 * c + 1) ^ (r0 & 7)) << 2);
+  const int mfirst = mrow0 + r0;
+  const int64_t ci0 = coff + (int64_t)(mfirst < p.M ? mfirst : p.M - 1) * p.ldc + n;      // (clamped: edge tiles)
+  const int64_t cstep = (int64_t)RSTEP * p.ldc;
+  const int rows_ok = mfirst < p.M ? (p.M - 1 - mfirst) / RSTEP : -1;                     // rows 0..rows_ok of this thread exist
 #pragma unroll
   for (int g0 = 0; g0 < NIT; g0 += G) {
     EpiOps x[G];
     int64_t ci[G];
 #pragma unroll
     for (int u = 0; u < G; ++u) {
-      int m = mrow0 + r0 + (g0 + u) * RSTEP;
-      m = m < p.M ? m : p.M - 1;                      // clamped for the loads; the store below is guarded
-      ci[u] = coff + (int64_t)m * p.ldc + n;
+      ci[u] = (g0 + u) <= rows_ok ? ci0 + (g0 + u) * cstep : ci0;      // clamped for the loads; the store below is guarded
       x[u].pre0 = x[u].pre1 = x[u].res0 = x[u].res1 = x[u].old0 = x[u].old1 = z4;
     }
     if (has_pre) {
@@ -248,10 +255,9 @@ __device__ __forceinline__ void epi_rows_k(const FArgs& p, const float* __restri
     }
 #pragma unroll
     for (int u = 0; u < G; ++u) {
-      const int r = r0 + (g0 + u) * RSTEP;
-      if (mrow0 + r >= p.M) continue;
-      const float4 lo = *reinterpret_cast<const float4*>(ct + r * BN_ + (((2 * c) ^ (r & 7)) << 2));
-      const float4 hi = *reinterpret_cast<const float4*>(ct + r * BN_ + (((2 * c + 1) ^ (r & 7)) << 2));
+      if ((g0 + u) > rows_ok) continue;
+      const float4 lo = *reinterpret_cast<const float4*>(ctl + (g0 + u) * (RSTEP * BN_));
+      const float4 hi = *reinterpret_cast<const float4*>(cth + (g0 + u) * (RSTEP * BN_));
       float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
       epi8_finish<ACT, GK>(p, bz0, bz1, x[u], ci[u], v);
     }

@@ -66,9 +66,9 @@ class GradSync:
         if hi <= lo or self.world == 1:
             return
         view = self._flat()[lo:hi]
-        if view.is_cuda:
+        if view.is_cuda and dist.get_backend(self.group) == "nccl":
             h = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-        else:                                     # gloo has no AVG
+        else:                                     # gloo has no AVG (CPU tests; GPU rehearsals of the N > 1 flow on one card)
             view.div_(self.world)
             h = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.handles.append(h)
