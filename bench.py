@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="replay the training step from a captured hipGraph (single GPU); measured equal to eager launches")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--host-input", action="store_true",
+                    help="train mode: copy each batch from pinned host memory (double-buffered side stream); PCIe-inclusive rate")
     return ap.parse_args()
 
 
@@ -205,8 +207,30 @@ def main():
             broadcast_parameters(model)
             model.refresh_shadow()
 
-        def step():
-            stepper.step(x, target, cam)
+        if a.host_input:
+            # PCIe-inclusive variant (NOT the contract's `value`): the batch lives in pinned host memory, as train_collate_fn
+            # would leave it, and is copied to one of two device buffers on a side stream while the previous step computes
+            host = {k: v.cpu().pin_memory() for k, v in x.items()}
+            bufs = [{k: torch.empty_like(v) for k, v in x.items()} for _ in range(2)]
+            copy_stream, ready, turn = torch.cuda.Stream(), [torch.cuda.Event(), torch.cuda.Event()], [0]
+
+            def upload(i):
+                copy_stream.wait_stream(torch.cuda.current_stream())      # the buffer's previous consumer has been queued
+                with torch.cuda.stream(copy_stream):
+                    for k in host:
+                        bufs[i][k].copy_(host[k], non_blocking=True)
+                    ready[i].record()
+            upload(0)
+
+            def step():
+                i = turn[0]
+                torch.cuda.current_stream().wait_event(ready[i])
+                upload(1 - i)                                             # next batch flies under this step
+                stepper.step(bufs[i], target, cam)
+                turn[0] = 1 - i
+        else:
+            def step():
+                stepper.step(x, target, cam)
 
         def eager_step():                      # the instrumented pass must see every launch: no graph replay
             stepper._run(x, target, cam, stepper.hyper if stepper.use_graph else None)
@@ -266,7 +290,9 @@ def main():
                                     + ("train step fwd+bwd, " if mode == "train" else "eval forward, ")
                                     + f"3x({B},3,256,128) per GPU, random-init weights"),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "mode": mode,
-                       "launch": "hipGraph replay" if (mode == "train" and stepper.use_graph) else "eager"},
+                       "launch": "hipGraph replay" if (mode == "train" and stepper.use_graph) else "eager",
+                       "input": "pinned host memory, copied every step (PCIe-inclusive)" if (mode == "train" and a.host_input)
+                       else "resident in HBM"},
             "model_tflops": round(val * flop_per_triplet / 1e12, 1),
             "roofline": roof, "cpu_baseline": cpu,
         }
