@@ -98,3 +98,35 @@ def test_cabi_exports_every_declared_symbol():
     assert set(_lib.PROTOTYPES) | {"demo_last_error"} == set(declared)
     assert _lib.load().demo_abi_version() == 1
     assert ctypes.sizeof(_lib.GemmDesc) == _lib.load().demo_gemm_desc_size()
+
+
+def test_evaluator_host_aggregation_matches_oracle(monkeypatch):
+    """demo2_amd.utils.metrics: everything around the rank_eval kernel (id upload, valid-query mask, CMC from first-hit ranks,
+    mean AP) against the oracle's eval_func, with the kernel replaced by a numpy stand-in producing its (ap, first_hit)."""
+    import numpy as np
+    from demo2_amd.utils import metrics as M
+    from oracle import demo_oracle as O
+
+    rng = np.random.default_rng(0)
+    nq, ng = 23, 97
+    dist = rng.random((nq, ng)).astype(np.float32)
+    q_pids, g_pids = rng.integers(0, 9, nq), rng.integers(0, 8, ng)       # identity 8 never appears in the gallery
+    q_cam, g_cam = rng.integers(0, 3, nq), rng.integers(0, 3, ng)
+
+    def fake_rank_eval(distmat, qp, gp, qk, gk, want_order=False):
+        d, qp, gp, qk, gk = (t.cpu().numpy() for t in (distmat, qp, gp, qk, gk))
+        ap, first = np.full(nq, -1.0), np.full(nq, -1, dtype=np.int32)
+        for i in range(nq):
+            order = np.argsort(d[i], kind="stable")
+            keep = ~((gp[order] == qp[i]) & (gk[order] == qk[i]))
+            m = (gp[order] == qp[i])[keep].astype(np.int64)
+            if m.any():
+                first[i] = int(np.argmax(m))
+                ap[i] = ((m.cumsum() / (np.arange(m.size) + 1.0)) * m).sum() / m.sum()
+        return torch.from_numpy(ap), torch.from_numpy(first)
+
+    monkeypatch.setattr(M.ops, "rank_eval", fake_rank_eval)
+    cmc, mAP = M._rank_metrics(torch.from_numpy(dist), q_pids, g_pids, q_cam, g_cam, 20)
+    cmc_ref, map_ref = O.eval_market1501(dist, q_pids, g_pids, q_cam, g_cam, 20)
+    np.testing.assert_allclose(cmc, cmc_ref, atol=1e-7)
+    assert abs(mAP - map_ref) < 1e-12
