@@ -66,7 +66,8 @@ PROTOTYPES = {
     "demo_hdm_softmax_pool_bwd": [_P, _P, _P, _P, _I, _P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _U64, _P, _P],
     "demo_hdm_vbias_bwd": [_P, _P, _L, _P, _P, _P, _I, _I, _I, _P],
     "demo_atmoe_gate_softmax_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "demo_gemm_tn_bf16": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _F, _I, _P, _P],
+    "demo_gemm_tn_bf16": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _F, _I, _P, _P, _L, _P],
+    "demo_gemm_tn_workspace": [_I, _I, _I],
     "demo_attention_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "demo_embed_tokens_bwd": [_P, _P, _F, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P],
     "demo_act_bwd": [_P, _P, _I, _P, _L, _P],
@@ -108,6 +109,7 @@ def load():
         fn.argtypes = argtypes
         fn.restype = C.c_int
     lib.demo_layernorm_bwd_workspace.restype = C.c_int64
+    lib.demo_gemm_tn_workspace.restype = C.c_int64
     lib.demo_last_error.argtypes = []
     lib.demo_last_error.restype = C.c_char_p
     if lib.demo_gemm_desc_size() != C.sizeof(GemmDesc):

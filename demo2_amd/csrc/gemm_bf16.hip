@@ -704,10 +704,11 @@ int demo_gemm_bf16_eligible(const demo_gemm_desc& d) {
 
 static int g_force_tile = 0;   // test/bench hook: 128 or 256 forces a configuration, 0 = heuristic
 void demo_gemm_tn_force(int t);
-// 1280: only pins the weight-gradient (TN) product to its 128^2 form; 0 restores the heuristics of both
+// 1280: only pins the weight-gradient (TN) product to its 128^2 form, 1290: to the 256^2 form with fp32 atomics (no two-pass
+// split-K); 0 restores the heuristics of both
 extern "C" int demo_gemm_force_tile(int t) {
-  g_force_tile = t == 1280 ? 0 : t;
-  demo_gemm_tn_force(t == 1280 ? 128 : 0);
+  g_force_tile = (t == 1280 || t == 1290) ? 0 : t;
+  demo_gemm_tn_force(t == 1280 ? 128 : t == 1290 ? 129 : 0);
   return 0;
 }
 

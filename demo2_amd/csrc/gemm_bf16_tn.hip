@@ -38,6 +38,7 @@ struct TArgs {
   int use_atomics;      // 1: atomicAdd into C; 0: C = (accumulate ? C : 0) + result with plain stores
   int accumulate;
   float* colsum;        // optional: colsum[m] += sum_r A[r, m]  (the bias gradient of the same Linear), atomics
+  float* partial;       // 256^2 form, optional: (splitk, Mo, No) workspace -> slices store plain partial tiles, summed by a 2nd pass
 };
 
 // LDS-DMA staging of a full 64-row tile: rows [k0, k0+64) x cols [c0, c0+128)
@@ -399,13 +400,40 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_pp_kernel(const TArgs p) 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wr * 128 + ((i & 4) + ((i + wc) & 3)) * 16 + 4 * g + r;      // rotated row-tile order
-        float* c = p.C + (int64_t)m * p.ldc + n;
         const float v = acc[i][j][r] * p.alpha;
+        if (p.partial) {                                     // slice `split` of the partial-tile workspace, plain stores
+          p.partial[((int64_t)split * p.Mo + m) * p.No + n] = v;
+          continue;
+        }
+        float* c = p.C + (int64_t)m * p.ldc + n;
         if (p.use_atomics) atomicAdd(c, v);
         else *c = p.accumulate ? *c + v : v;
       }
     }
   }
+}
+
+// second pass of the two-pass split-K form: C (+)= sum over slices of the partial tiles.  One float4 of C per thread.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ partial, int splitk, int Mo, int No, float* __restrict__ C,
+                                                        int64_t ldc, int accumulate) {
+  const int64_t q = blockIdx.x * 256 + threadIdx.x;         // float4 index inside the (Mo, No) tile image
+  const int64_t total4 = (int64_t)Mo * No / 4;
+  if (q >= total4) return;
+  const int64_t slice4 = total4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* p4 = reinterpret_cast<const float4*>(partial) + q;
+#pragma unroll 4
+  for (int k = 0; k < splitk; ++k) {
+    const float4 v = p4[k * slice4];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const int64_t e = q * 4, m = e / No, n = e - m * No;
+  float4* c = reinterpret_cast<float4*>(C + m * ldc + n);
+  if (accumulate) {
+    const float4 o = *c;
+    s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+  }
+  *c = s;
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -415,8 +443,21 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 static int g_tn_force = 0;     // bench hook (shared with demo_gemm_force_tile): 128 forces the 128^2 form
 void demo_gemm_tn_force(int t) { g_tn_force = t; }
 
+// floats of workspace with which demo_gemm_tn_bf16 takes the two-pass split-K form for this shape (0: it would not split)
+extern "C" int64_t demo_gemm_tn_workspace(int32_t Mo, int32_t No, int32_t Kr) {
+  if (Mo <= 0 || No <= 0 || Kr < 2048 || Mo % PBM || No % PBN) return 0;
+  const int tiles = (Mo / PBM) * (No / PBN);
+  const int kstages = (Kr + PBK - 1) / PBK;
+  int splitk = tiles >= 256 ? 1 : 256 / tiles;
+  if (splitk > kstages / 16) splitk = kstages / 16 > 0 ? kstages / 16 : 1;
+  const int per = (kstages + splitk - 1) / splitk;
+  splitk = (kstages + per - 1) / per;
+  return splitk > 1 ? (int64_t)splitk * Mo * No : 0;
+}
+
 extern "C" int demo_gemm_tn_bf16(const void* A, const void* B, float* C, int32_t Mo, int32_t No, int32_t Kr, int64_t lda, int64_t ldb,
-                                 int64_t ldc, float alpha, int32_t accumulate, float* colsum, void* stream) {
+                                 int64_t ldc, float alpha, int32_t accumulate, float* colsum, float* workspace, int64_t workspace_elems,
+                                 void* stream) {
   DEMO_REQUIRE(A && B && C, "demo_gemm_tn_bf16: null operand");
   DEMO_REQUIRE(Mo > 0 && No > 0 && Kr > 0 && Mo % BM == 0 && No % BN == 0, "demo_gemm_tn_bf16: Mo=%d No=%d must be multiples of 128", Mo, No);
   DEMO_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && al16(A) && al16(B), "demo_gemm_tn_bf16: operands must be 16-B aligned with ld %% 8 == 0");
@@ -424,6 +465,7 @@ extern "C" int demo_gemm_tn_bf16(const void* A, const void* B, float* C, int32_t
   TArgs p;
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
   p.Mo = Mo; p.No = No; p.Kr = Kr; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.alpha = alpha;
+  p.partial = nullptr;
   if (g_tn_force != 128 && Mo % PBM == 0 && No % PBN == 0 && Kr >= 2048) {
     // 256^2 ping-pong form: split the reduction so that the grid is about one round of the 256 CUs
     p.ntm = Mo / PBM; p.ntn = No / PBN;
@@ -440,7 +482,14 @@ extern "C" int demo_gemm_tn_bf16(const void* A, const void* B, float* C, int32_t
     p.accumulate = accumulate;
     p.colsum = colsum;
     p.part_m = 0;
-    if (p.use_atomics && !accumulate) {
+    // Two-pass split-K when the caller lends a workspace: every slice stores its 256x256 partial tile with plain stores and a
+    // second small kernel sums the slices into C.  With fp32 atomics straight into C the ~16.5 M element-atomics of a launch
+    // (252 workgroups x 65536) run at the L2 atomic units' rate, ~60 us per launch whatever the split count; the partial
+    // image (<= 66 MB) is written and re-read at HBM speed instead.
+    const int64_t need = (int64_t)p.splitk * Mo * No;
+    const bool two_pass = p.splitk > 1 && workspace && workspace_elems >= need && (ldc % 4 == 0) && al16(C) && g_tn_force != 129;
+    if (two_pass) p.partial = workspace;
+    if (p.use_atomics && !accumulate && !two_pass) {
       hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)No * sizeof(float), (size_t)Mo, s);
       if (e != hipSuccess) DEMO_FAIL(-2, "demo_gemm_tn_bf16: memset failed: %s", hipGetErrorString(e));
     }
@@ -448,6 +497,11 @@ extern "C" int demo_gemm_tn_bf16(const void* A, const void* B, float* C, int32_t
     if (colsum) hipLaunchKernelGGL(gemm_bf16_tn_pp_kernel<true>, dim3(nwg), dim3(512), 0, s, p);
     else hipLaunchKernelGGL(gemm_bf16_tn_pp_kernel<false>, dim3(nwg), dim3(512), 0, s, p);
     DEMO_LAUNCH_CHECK("demo_gemm_tn_bf16(256)");
+    if (two_pass) {
+      hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv64((int64_t)Mo * No / 4, 256)), dim3(256), 0, s, workspace, p.splitk, Mo, No, C,
+                         ldc, accumulate);
+      DEMO_LAUNCH_CHECK("demo_gemm_tn_bf16(reduce)");
+    }
     return 0;
   }
   p.ntm = Mo / BM; p.ntn = No / BN;

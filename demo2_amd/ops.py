@@ -257,6 +257,7 @@ def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, 
 
 
 _LN_WS = {}
+_TN_WS = {}        # per device: partial-tile workspace of the two-pass split-K weight-gradient GEMM
 
 
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, shadow: Optional[Tensor], lr: float, beta1: float, beta2: float, eps: float,
@@ -396,8 +397,15 @@ def gemm_tn(a: Tensor, b: Tensor, out: Tensor, out_off: int = 0, ldc: Optional[i
     if (a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and Mo % 128 == 0 and No % 128 == 0 and a.stride(1) == 1
             and b.stride(1) == 1 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
         cs = None if colsum_out is None else colsum_out.data_ptr() + 4 * colsum_off
-        check(_lib.load().demo_gemm_tn_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr() + 4 * out_off, Mo, No, R, a.stride(0), b.stride(0), ldc,
-                                            float(alpha), int(accumulate), cs, _stream()), "demo_gemm_tn_bf16")
+        lib = _lib.load()
+        # partial-tile workspace of the two-pass split-K form (one per device, grown to the largest request: <= 66 MB)
+        need = int(lib.demo_gemm_tn_workspace(Mo, No, R))
+        ws = _TN_WS.get(a.device)
+        if need and (ws is None or ws.numel() < need):
+            ws = _TN_WS[a.device] = torch.empty(need, device=a.device, dtype=torch.float32)
+        check(lib.demo_gemm_tn_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr() + 4 * out_off, Mo, No, R, a.stride(0), b.stride(0), ldc,
+                                    float(alpha), int(accumulate), cs, _ptr(ws) if need else None, ws.numel() if (need and ws is not None) else 0,
+                                    _stream()), "demo_gemm_tn_bf16")
         return out
     if colsum_out is not None:                      # bias gradient: colsum_out[colsum_off + m] += sum_r a[r, m]
         colsum(a, out=colsum_out[colsum_off:colsum_off + Mo], accumulate=True)

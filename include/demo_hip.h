@@ -177,7 +177,11 @@ int demo_atmoe_gate_softmax_bwd(const float* dgates, const float* gates, const f
  * C[Mo,No] (+)= alpha * sum_r A[r,Mo] * B[r,No]; bf16 MFMA, split over the reduction with fp32 atomics.
  * dW of every nn.Linear in the trunk: A = dY (rows,N), B = X (rows,K) -> C = dW (N,K) inside the flat grad buffer. */
 int demo_gemm_tn_bf16(const void* A, const void* B, float* C, int32_t Mo, int32_t No, int32_t Kr, int64_t lda, int64_t ldb,
-                      int64_t ldc, float alpha, int32_t accumulate, float* colsum, void* stream);
+                      int64_t ldc, float alpha, int32_t accumulate, float* colsum, float* workspace, int64_t workspace_elems,
+                      void* stream);
+/* floats of `workspace` with which the call above combines its reduction slices in two passes (plain partial tiles + a small
+ * summing kernel) instead of fp32 atomics into C; 0 if the shape is not split.  workspace may be NULL (atomics). */
+int64_t demo_gemm_tn_workspace(int32_t Mo, int32_t No, int32_t Kr);
 /* colsum (optional, fp32 [Mo]): colsum[m] += sum_r A[r,m] -- the bias gradient of the same Linear, computed by the waves
  * that already hold the A fragments (no extra pass over dY). */
 /* Self-attention backward (same packing as demo_attention_fwd; lse from the forward): dqkv (Bn*L, 3D). */

@@ -24,7 +24,7 @@ for (rows, n, k) in [(2048, 256, 256), (2050, 512, 256), (3097, 256, 768), (4100
     x = torch.randn(rows, k, device=dev).bfloat16()
     ref = dy.float().t() @ x.float()
     refb = dy.float().sum(0)
-    for force in (0, 1280):
+    for force in (0, 1280, 1290):
         lib.demo_gemm_force_tile(force)
         g = torch.zeros(n, k, device=dev)
         bsum = torch.zeros(n, device=dev)
@@ -36,7 +36,7 @@ for (rows, n, k) in [(2048, 256, 256), (2050, 512, 256), (3097, 256, 768), (4100
         e3 = ((bsum - refb).abs().max() / refb.abs().max()).item()
         ok = e1 < 2e-3 and e2 < 2e-3 and e3 < 2e-3
         bad += not ok
-        print(f"check rows={rows} n={n} k={k} form={'128' if force else 'auto'}: {e1:.1e} {e2:.1e} colsum {e3:.1e} {'OK' if ok else 'FAIL'}")
+        print(f"check rows={rows} n={n} k={k} form={ {0: 'auto', 1280: '128', 1290: '256-atomic'}[force]}: {e1:.1e} {e2:.1e} colsum {e3:.1e} {'OK' if ok else 'FAIL'}")
 lib.demo_gemm_force_tile(0)
 if bad:
     sys.exit(1)
@@ -63,11 +63,12 @@ for name, n, k in [("qkv", 3 * W, W), ("proj", W, W), ("fc1", 4 * W, W), ("fc2",
     bsum = torch.zeros(n, device=dev)
     res = {}
     for rnd in range(3):
-        for force in (1280, 0):
+        for force in (1280, 1290, 0):
             lib.demo_gemm_force_tile(force)
             ms = timeit(lambda: ops.gemm_tn(dy, x, g, accumulate=True, colsum_out=bsum), a.reps)
             res.setdefault(force, []).append(ms)
     lib.demo_gemm_force_tile(0)
     fl = 2.0 * M * n * k
     print(f"TN {name:5s} out {n}x{k}: 128^2 {min(res[1280]) * 1e3:7.1f} us {fl / min(res[1280]) / 1e9:6.0f} TF   "
-          f"256^2 {min(res[0]) * 1e3:7.1f} us {fl / min(res[0]) / 1e9:6.0f} TF", flush=True)
+          f"256^2 atomics {min(res[1290]) * 1e3:7.1f} us {fl / min(res[1290]) / 1e9:6.0f} TF   "
+          f"256^2 two-pass {min(res[0]) * 1e3:7.1f} us {fl / min(res[0]) / 1e9:6.0f} TF", flush=True)
