@@ -300,29 +300,70 @@ def trunk_backward(m, tape, dtokens):
     if sync is not None:
         sync.tail_ready()
     # ---- blocks in reverse ---------------------------------------------------------------------------------------------
+    # Weight gradients (dW = dY^T X) feed nothing in the backward chain, so in bf16 mode they go to a SIDE stream: their
+    # workgroups fill the CUs the dX GEMMs leave idle in their last partial round (582 tiles on 256 CUs = 2.27 rounds for the
+    # N = 768 products) and the dispatch gaps between the dependent launches of the main chain.  Opt-in (DEMO_OVERLAP_DW=1):
+    # measured 41.9 vs 42.5 ms per step at B = 128 -- both GEMM families hold a whole CU's LDS per workgroup, so the two
+    # queues mostly alternate instead of sharing CUs -- and per-kernel timings (bench.py roofline, rocprofv3) stop being
+    # the kernels' own rates once they overlap, so the default stays single-stream.
+    side = m.side_stream() if (lp and m.overlap_dw and not torch.cuda.is_current_stream_capturing()) else None
+    main = torch.cuda.current_stream() if side is not None else None
+    dxbs = [dxb, torch.empty_like(dxb)] if side is not None else [dxb, dxb]    # the LayerNorm backward alternates its bf16 output
+    readers = [None, None]                                                      # last side-stream reader of each of them
+    cur = 0
+
+    def dw(a_t, b_t, key_w, ldc, key_b, buf=None):
+        """dW (+ bias gradient) of one Linear; on the side stream when there is one."""
+        if side is None:
+            ops.gemm_tn(a_t, b_t, G, out_off=P.off(key_w), ldc=ldc, accumulate=True, colsum_out=G, colsum_off=P.off(key_b))
+            return
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.gemm_tn(a_t, b_t, G, out_off=P.off(key_w), ldc=ldc, accumulate=True, colsum_out=G, colsum_off=P.off(key_b))
+            if buf is not None:
+                readers[buf] = torch.cuda.Event()
+                readers[buf].record(side)
+        a_t.record_stream(side)                    # the caching allocator must not hand these out again before the side
+        b_t.record_stream(side)                    # stream has read them
+
+    def next_dxb():
+        """bf16 gradient buffer the next LayerNorm backward may overwrite: its last reader on the side stream has finished."""
+        nonlocal cur
+        cur ^= 1
+        if side is not None and readers[cur] is not None:
+            main.wait_event(readers[cur])
+            readers[cur] = None
+        return dxbs[cur]
+
     for i in reversed(range(g.layers)):
         k, s = g.block_keys(i), tape.blocks[i]
-        d_res = dxb if lp else dx                                   # gradient of the block output, GEMM operand dtype
+        d_res = dxbs[cur] if lp else dx                             # gradient of the block output, GEMM operand dtype
         # x2 = x1 + fc2(u)
-        ops.gemm_tn(d_res, s["u"], G, out_off=P.off(k["fc2_w"]), ldc=4 * W, accumulate=True, colsum_out=G, colsum_off=P.off(k["fc2_b"]))
+        dw(d_res, s["u"], k["fc2_w"], 4 * W, k["fc2_b"], buf=cur)
         dpre = ops.gemm(d_res, P.wt(k["fc2_w"], T), act_grad_pre=s["pre"], act_grad_kind=act)      # (M, 4W) = (dx W2) * act'(pre)
         # u = act(fc1(h2))
-        ops.gemm_tn(dpre, s["h2"], G, out_off=P.off(k["fc1_w"]), ldc=W, accumulate=True, colsum_out=G, colsum_off=P.off(k["fc1_b"]))
+        dw(dpre, s["h2"], k["fc1_w"], W, k["fc1_b"])
         dh2 = ops.gemm(dpre, P.wt(k["fc1_w"], T))                                                  # (M, W)
+        nb = next_dxb() if lp else None
         ops.layernorm_bwd(dh2, s["x1"], P.f(k["ln2"] + ".weight"), s["mean2"], s["rstd2"], dx=dx, accumulate_dx=True,
-                          dw=gw(k["ln2"] + ".weight"), db=gw(k["ln2"] + ".bias"), dx_lp=dxb)
-        d_res = dxb if lp else dx
+                          dw=gw(k["ln2"] + ".weight"), db=gw(k["ln2"] + ".bias"), dx_lp=nb)
+        d_res = nb if lp else dx
         # x1 = x + out_proj(a)
-        ops.gemm_tn(d_res, s["a"], G, out_off=P.off(k["proj_w"]), ldc=W, accumulate=True, colsum_out=G, colsum_off=P.off(k["proj_b"]))
+        dw(d_res, s["a"], k["proj_w"], W, k["proj_b"], buf=cur)
         da = ops.gemm(d_res, P.wt(k["proj_w"], T))                                                 # (M, W)
         dqkv = ops.attention_bwd(s["qkv"], s["a"], da, s["lse"], Bn, L, g.heads)                   # (M, 3W)
-        ops.gemm_tn(dqkv, s["h1"], G, out_off=P.off(k["qkv_w"]), ldc=W, accumulate=True, colsum_out=G, colsum_off=P.off(k["qkv_b"]))
+        dw(dqkv, s["h1"], k["qkv_w"], W, k["qkv_b"])
         dh1 = ops.gemm(dqkv, P.wt(k["qkv_w"], T))                                                  # (M, W)
+        nb = next_dxb() if lp else None
         ops.layernorm_bwd(dh1, s["x"], P.f(k["ln1"] + ".weight"), s["mean1"], s["rstd1"], dx=dx, accumulate_dx=True,
-                          dw=gw(k["ln1"] + ".weight"), db=gw(k["ln1"] + ".bias"), dx_lp=dxb)
+                          dw=gw(k["ln1"] + ".weight"), db=gw(k["ln1"] + ".bias"), dx_lp=nb)
         tape.blocks[i] = None                                       # release the activations of this block
         if sync is not None:
+            if side is not None:
+                main.wait_stream(side)                              # this block's weight gradients are final
             sync.block_ready(i)
+    if side is not None:
+        main.wait_stream(side)
     # ---- embedding ----------------------------------------------------------------------------------------------------
     if g.k_lnpre:
         dpre = ops.layernorm_bwd(dx, t["emb_pre"], P.f(g.k_lnpre + ".weight"), t["emb_mean"], t["emb_rstd"], dw=gw(g.k_lnpre + ".weight"),

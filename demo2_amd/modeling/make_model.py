@@ -148,6 +148,8 @@ class DeMo(_Holder):
         self._anchor = None
         self._frozen = None
         self.grad_sync = None            # set by demo2_amd.dist.GradSync for data-parallel runs
+        self.overlap_dw = os.environ.get("DEMO_OVERLAP_DW", "0") == "1"   # opt-in: weight-gradient GEMMs on a side stream (hip_backward.py; measured +1.4 %)
+        self._side = None
         self.geom = self._make_geometry(cfg)
         self._flatten()
 
@@ -350,6 +352,13 @@ class DeMo(_Holder):
             t = (torch.zeros if zero else torch.empty)(*shape, device=self.ptab.flat.device, dtype=dtype)
             self._ws[key] = t
         return t
+
+    def side_stream(self):
+        """Second HIP stream of the model's device (weight-gradient GEMMs run there beside the dX chain)."""
+        dev = self.ptab.flat.device
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
 
     def next_seed(self) -> int:
         self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) & (2 ** 64 - 1)

@@ -398,11 +398,12 @@ def gemm_tn(a: Tensor, b: Tensor, out: Tensor, out_off: int = 0, ldc: Optional[i
             and b.stride(1) == 1 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
         cs = None if colsum_out is None else colsum_out.data_ptr() + 4 * colsum_off
         lib = _lib.load()
-        # partial-tile workspace of the two-pass split-K form (one per device, grown to the largest request: <= 66 MB)
+        # partial-tile workspace of the two-pass split-K form (one per device and stream, grown to the largest request: <= 66 MB)
         need = int(lib.demo_gemm_tn_workspace(Mo, No, R))
-        ws = _TN_WS.get(a.device)
+        wkey = (a.device, _stream())                 # per stream: concurrent launches on two streams must not share it
+        ws = _TN_WS.get(wkey)
         if need and (ws is None or ws.numel() < need):
-            ws = _TN_WS[a.device] = torch.empty(need, device=a.device, dtype=torch.float32)
+            ws = _TN_WS[wkey] = torch.empty(need, device=a.device, dtype=torch.float32)
         check(lib.demo_gemm_tn_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr() + 4 * out_off, Mo, No, R, a.stride(0), b.stride(0), ldc,
                                     float(alpha), int(accumulate), cs, _ptr(ws) if need else None, ws.numel() if (need and ws is not None) else 0,
                                     _stream()), "demo_gemm_tn_bf16")
