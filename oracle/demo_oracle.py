@@ -58,6 +58,9 @@ class Spec:
     direct: int = 1
     miss: str = "nothing"
     hdm_dropout: float = 0.1      # AttnMOE.py:125 default, make_model.py:132 does not override
+    use_dgaf: bool = False        # cfg.MODEL.USE_DGAF with DGAF_VERSION 'v3', no SDTPS/FRCA (make_model.py:835-865, "branch 3")
+    dgaf_heads: int = 8           # cfg.MODEL.DGAF_NUM_HEADS (config/defaults.py:62)
+    dgaf_tau: float = 1.0         # cfg.MODEL.DGAF_TAU (config/defaults.py:60)
     bn_eps: float = 1e-5
     bn_momentum: float = 0.1
 
@@ -285,6 +288,46 @@ def general_fusion(sd: SD, caches, globs, spec: Spec, training: bool, updates: O
     return torch.cat(feats, -1)
 
 
+def dgaf_v3(sd: SD, p: str, caches: Sequence[Tensor], heads: int, tau: float, taps: Optional[dict] = None) -> Tensor:
+    """DualGatedAdaptiveFusionV3.forward with output_dim = 3C (modeling/dual_gated_fusion.py:558-745):
+    attention pooling of each modality's patch tokens by a learned query through ONE shared nn.MultiheadAttention
+    (:661-679, no dropout) + LayerNorm, entropy gate IEG (:681-719), importance gate MIG (:721-730), sigmoid(alpha)
+    blend (:732-734), LayerNorm(Linear) enhancement added to every pooled modality feature, concatenated (:739-745)."""
+    C = caches[0].shape[-1]
+    dh = C // heads
+    w, b = sd[p + "attn_pool.in_proj_weight"], sd[p + "attn_pool.in_proj_bias"]
+    hs = []
+    for name, x in zip(("rgb_query", "nir_query", "tir_query"), caches):
+        B, N, _ = x.shape
+        q = linear(sd[p + name].reshape(1, C), w[:C], b[:C]).reshape(heads, dh) * (dh ** -0.5)
+        k = linear(x, w[C:2 * C], b[C:2 * C]).reshape(B, N, heads, dh)
+        v = linear(x, w[2 * C:], b[2 * C:]).reshape(B, N, heads, dh)
+        att = torch.einsum("hd,bnhd->bhn", q, k).softmax(-1)
+        o = torch.einsum("bhn,bnhd->bhd", att, v).reshape(B, C)
+        o = linear(o, sd[p + "attn_pool.out_proj.weight"], sd[p + "attn_pool.out_proj.bias"])
+        hs.append(layer_norm(o, sd[p + "attn_norm.weight"], sd[p + "attn_norm.bias"], 1e-5))          # :677
+    scores = []
+    for h in hs:
+        a = h.abs() + 1e-8                                                                            # :683-686
+        prob = a / a.sum(-1, keepdim=True)
+        ent = -(prob * torch.log(prob + 1e-8)).sum(-1)
+        z = linear(h, sd[p + "entropy_proj.weight"], sd[p + "entropy_proj.bias"]).mean(-1)            # :705-707
+        scores.append(z * torch.exp(-ent / tau))                                                      # :709-711
+    ew = torch.stack(scores, -1).softmax(-1)                                                          # :713-714
+    h_entropy = sum(ew[:, i:i + 1] * hs[i] for i in range(3))
+    g = linear(torch.cat(hs, -1), sd[p + "gate_net.0.weight"], sd[p + "gate_net.0.bias"])             # :609-615
+    g = torch.relu(layer_norm(g, sd[p + "gate_net.1.weight"], sd[p + "gate_net.1.bias"], 1e-5))
+    gates = torch.sigmoid(linear(g, sd[p + "gate_net.3.weight"], sd[p + "gate_net.3.bias"]))
+    h_importance = sum(gates[:, i:i + 1] * hs[i] for i in range(3))
+    alpha = torch.sigmoid(sd[p + "_alpha"])                                                           # :640-643
+    fused = alpha * h_entropy + (1 - alpha) * h_importance
+    enh = layer_norm(linear(fused, sd[p + "modal_enhance.0.weight"], sd[p + "modal_enhance.0.bias"]),
+                     sd[p + "modal_enhance.1.weight"], sd[p + "modal_enhance.1.bias"], 1e-5)
+    if taps is not None:
+        taps.update(dgaf_h=hs, dgaf_ew=ew, dgaf_gates=gates, dgaf_fused=fused, dgaf_enh=enh)
+    return torch.cat([h + enh for h in hs], -1)
+
+
 def bnneck_head(sd: SD, bn: str, cls: str, x: Tensor, spec: Spec, training: bool,
                 updates: Optional[SD] = None) -> Tensor:
     """classifier(bottleneck(x)) (make_model.py:134-138,174-194)."""
@@ -306,6 +349,18 @@ def model_forward(sd: SD, spec: Spec, x: Dict[str, Tensor], cam_label: Optional[
         c, g = backbone(sd, im, cam_label, spec)
         caches.append(c)
         globs.append(g)
+    if spec.use_dgaf:
+        # class DeMo, "branch 3" (make_model.py:835-865): DGAF-V3 on the raw patch tokens; the globals are the raw cls rows
+        feat = dgaf_v3(sd, "dgaf.", caches, spec.dgaf_heads, spec.dgaf_tau, taps)
+        if taps is not None:
+            taps.update(caches=caches, globs=globs, dgaf_feat=feat)
+        if not training:
+            return feat
+        res = (bnneck_head(sd, "bottleneck_dgaf", "classifier_dgaf", feat, spec, True, updates), feat)
+        if not spec.direct:
+            for s_, g in zip("rnt", globs):
+                res += (bnneck_head(sd, f"bottleneck_{s_}", f"classifier_{s_}", g, spec, True, updates), g)
+        return res
     if spec.global_local:                                             # :301-303
         globs = [pife_reduce(sd, n, g, c, spec) for n, g, c in zip(("rgb_reduce", "nir_reduce", "tir_reduce"), globs, caches)]
     ori = torch.cat(globs, -1)                                        # :370
@@ -496,6 +551,23 @@ def init_state_dict(spec: Spec, seed: int = 0, scale_rand_bn: bool = True) -> SD
             lin(gk + "k_", C, C, bias=False)
         lin("classifier_moe", spec.num_classes, 7 * C, bias=False, std=0.02)
         bn("bottleneck_moe", 7 * C)
+    if spec.use_dgaf:                                                 # dual_gated_fusion.py:586-637, make_model.py:630-634
+        d = "dgaf."
+        for n in ("rgb_query", "nir_query", "tir_query"):
+            sd[d + n] = rn(1, 1, C, std=1.0)
+        sd[d + "attn_pool.in_proj_weight"] = rn(3 * C, C, std=C ** -0.5)
+        sd[d + "attn_pool.in_proj_bias"] = rn(3 * C, std=0.02)
+        lin(d + "attn_pool.out_proj", C, C)
+        ln(d + "attn_norm", C)
+        lin(d + "entropy_proj", C, C)
+        lin(d + "gate_net.0", C, 3 * C)
+        ln(d + "gate_net.1", C)
+        lin(d + "gate_net.3", 3, C)
+        sd[d + "_alpha"] = torch.tensor(0.3)
+        lin(d + "modal_enhance.0", C, C)
+        ln(d + "modal_enhance.1", C)
+        lin("classifier_dgaf", spec.num_classes, 3 * C, bias=False, std=0.02)
+        bn("bottleneck_dgaf", 3 * C)
     if spec.direct:
         lin("classifier", spec.num_classes, 3 * C, bias=False, std=0.02)
         bn("bottleneck", 3 * C)

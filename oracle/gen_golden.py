@@ -140,6 +140,40 @@ def gen_fusion(ref, C=128, H=4, n_tok=8, tag="fusion_c128_h4", with_grads=False)
     _save(tag, **arrays)
 
 
+def gen_dgaf(tag="dgaf_v3_c64_h4"):
+    """DualGatedAdaptiveFusionV3 (modeling/dual_gated_fusion.py:558-745), output_dim = 3C: forward at B in {1,3} and
+    a backward (gradients w.r.t. inputs and every parameter) under a fixed random cotangent."""
+    dg = _load("ref_dual_gated_fusion", "modeling/dual_gated_fusion.py")
+    torch.manual_seed(41)
+    gen = torch.Generator().manual_seed(43)
+    C, H, K = 64, 4, 9
+    m = dg.DualGatedAdaptiveFusionV3(feat_dim=C, output_dim=3 * C, tau=0.7, init_alpha=0.3, num_heads=H)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("bias"):
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.05)     # defaults are zero
+            if ("norm" in n or n in ("gate_net.1.weight", "modal_enhance.1.weight")) and n.endswith("weight"):
+                p.copy_(1 + torch.randn(p.shape, generator=gen) * 0.05)
+            if n.endswith("_query"):
+                p.copy_(torch.randn(p.shape, generator=gen))            # the default scale C^-0.5 leaves the pooling nearly uniform
+    arrays = {"sd": _np(m.state_dict()), "meta": np.asarray([C, H, K, 0.7])}
+    m.eval()
+    for B in (1, 3):
+        ins = [torch.randn(B, K, C, generator=gen) for _ in range(3)]
+        with torch.no_grad():
+            out = m(*ins)
+        arrays[f"eval_b{B}"] = {**{f"in{i}": t.numpy() for i, t in enumerate(ins)}, "out": out.numpy()}
+    m.train()
+    ins = [torch.randn(4, K, C, generator=gen).requires_grad_(True) for _ in range(3)]
+    out = m(*ins)
+    w = torch.randn(out.shape, generator=gen)
+    (out * w).sum().backward()
+    arrays["train_b4"] = {**{f"in{i}": t.detach().numpy() for i, t in enumerate(ins)}, "out": out.detach().numpy(), "w": w.numpy(),
+                          **{f"gin{i}": t.grad.numpy() for i, t in enumerate(ins)}}
+    arrays["grads"] = {n: p.grad.numpy() for n, p in m.named_parameters() if p.grad is not None}
+    _save(tag, **arrays)
+
+
 def gen_clip(ref, tag="clip_w128_l2"):
     """CLIP VisionTransformer (forward_ori blocks), small: 4x2 patches, width 128, 2 layers."""
     torch.manual_seed(3)
@@ -236,6 +270,7 @@ def main():
     gen_pife(ref)
     gen_losses(ref)
     gen_eval()
+    gen_dgaf()
 
 
 if __name__ == "__main__":

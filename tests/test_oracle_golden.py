@@ -109,3 +109,27 @@ def test_model_forward_shapes():
     assert len(out) == 9
     loss = O.train_loss(out, torch.tensor([0, 0, 1, 1]))
     assert torch.isfinite(loss)
+
+
+def test_dgaf_v3(golden):
+    """DGAF-V3 restatement against the reference's DualGatedAdaptiveFusionV3 (modeling/dual_gated_fusion.py:558-745):
+    eval outputs, train output, gradients w.r.t. the three token streams and every parameter."""
+    g = golden("dgaf_v3_c64_h4")
+    C, H, K, tau = (float(v) for v in g["meta"])
+    H = int(H)
+    sd = _prefixed(g["sd"], "dgaf.")
+    for B in (1, 3):
+        e = g[f"eval_b{B}"]
+        out = O.dgaf_v3(sd, "dgaf.", [e[f"in{i}"] for i in range(3)], H, tau)
+        torch.testing.assert_close(out, e["out"], **TOL)
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    t = g["train_b4"]
+    ins = [t[f"in{i}"].clone().requires_grad_(True) for i in range(3)]
+    out = O.dgaf_v3(sd, "dgaf.", ins, H, tau)
+    torch.testing.assert_close(out, t["out"], **TOL)
+    (out * t["w"]).sum().backward()
+    for i in range(3):
+        torch.testing.assert_close(ins[i].grad, t[f"gin{i}"], rtol=1e-3, atol=1e-5)
+    assert set(g["grads"]) == {k[len("dgaf."):] for k in sd}
+    for k, v in g["grads"].items():
+        torch.testing.assert_close(sd["dgaf." + k].grad, v, rtol=1e-3, atol=2e-5)
