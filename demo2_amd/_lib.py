@@ -62,6 +62,12 @@ PROTOTYPES = {
     "demo_pife_pool_cat": [_P, _I, _P, _I, _I, _I, _P],
     "demo_set_token0": [_P, _I, _P, _L, _I, _I, _I, _P],
     "demo_get_token0": [_P, _I, _P, _L, _I, _I, _I, _P],
+    "demo_dgaf_attn_pool": [_P, _L, _P, _I, _P, _P, _I, _I, _I, _I, _P],
+    "demo_dgaf_attn_pool_bwd": [_P, _P, _P, _P, _I, _P, _L, _P, _I, _I, _I, _I, _P],
+    "demo_dgaf_gate_fuse": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _P],
+    "demo_dgaf_gate_fuse_bwd": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _P],
+    "demo_dgaf_combine": [_P, _P, _P, _I, _I, _P],
+    "demo_dgaf_sum3": [_P, _P, _I, _I, _P],
     "demo_hdm_softmax_pool": [_P, _L, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _U64, _P, _P],
     "demo_hdm_softmax_pool_bwd": [_P, _P, _P, _P, _I, _P, _P, _P, _L, _P, _I, _I, _I, _I, _F, _U64, _P, _P],
     "demo_hdm_vbias_bwd": [_P, _P, _L, _P, _P, _P, _I, _I, _I, _P],

@@ -102,6 +102,7 @@ def get_defaults() -> CfgNode:
             "ID_LOSS_WEIGHT": 1.0, "TRIPLET_LOSS_WEIGHT": 1.0, "METRIC_LOSS_TYPE": "triplet", "DIST_TRAIN": False,
             "PROMPT": False, "ADAPTER": False, "FROZEN": False, "HDM": False, "ATM": False,
             "USE_SACR": False, "USE_SDTPS": False, "USE_LIF": False, "USE_DGAF": False, "USE_MULTIMODAL_SACR": False,
+            "USE_FRCA": None, "DGAF_VERSION": "v3", "DGAF_TAU": 1.0, "DGAF_INIT_ALPHA": 0.5, "DGAF_NUM_HEADS": 8,
             "IF_LABELSMOOTH": "on", "DIRECT": 1, "DROP_PATH": 0.1, "DROP_OUT": 0.0, "ATT_DROP_RATE": 0.0,
             "TRANSFORMER_TYPE": "vit_base_patch16_224", "STRIDE_SIZE": [16, 16], "GLOBAL_LOCAL": False, "HEAD": 12,
             "SIE_COE": 3.0, "SIE_CAMERA": True, "SIE_VIEW": False, "NO_MARGIN": True,

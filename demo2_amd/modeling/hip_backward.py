@@ -43,12 +43,16 @@ def train_forward(m, imgs: List[torch.Tensor], cam: Optional[torch.Tensor]):
     tape.d["B"] = B
     T = m.compute_dtype
     tokens = HF.trunk_forward(m, imgs, cam, T, (), tape)
-    ori = HF.pife_forward(m, tokens, B, tape)
-    moe = None
-    if m.HDM:
-        feats = HF.hdm_forward(m, tokens, ori, B, True, tape)
-        moe = HF.atmoe_forward(m, feats, B, True, tape) if m.ATM else feats.view(B, -1)
-    outs = m._train_outputs(ori, moe, tape)
+    if m.USE_DGAF:
+        feat = HF.dgaf_forward(m, tokens, B, tape)
+        outs = m._train_outputs_dgaf(feat, None if m.direct else HF.cls_globals(m, tokens, B), tape)
+    else:
+        ori = HF.pife_forward(m, tokens, B, tape)
+        moe = None
+        if m.HDM:
+            feats = HF.hdm_forward(m, tokens, ori, B, True, tape)
+            moe = HF.atmoe_forward(m, feats, B, True, tape) if m.ATM else feats.view(B, -1)
+        outs = m._train_outputs(ori, moe, tape)
     tens = [o for o in outs if torch.is_tensor(o)]
     tape.d["n_out"] = len(tens)
     wrapped = list(_Boundary.apply(m, tape, m.anchor(), *tens))
@@ -95,7 +99,117 @@ def _zeros_like_or(gr, ref):
     return torch.zeros_like(ref) if gr is None else gr.contiguous().float().clone()
 
 
+def _model_backward_dgaf(m, tape, gouts):
+    """Backward of the DGAF-only branch: heads -> DGAF-V3 -> token gradients (+ cls gradients of the per-modality heads)."""
+    g = m.geom
+    B, C, L = tape.d["B"], g.feat_dim, g.n_patches + 1
+    gi = iter(gouts)
+    ds, dfe = next(gi), next(gi)
+    d_feat = _zeros_like_or(dfe, tape.d["head_dgaf"]["x"])
+    if ds is not None:
+        _head_backward(m, tape, "dgaf", ds.contiguous().float(), d_feat)
+    d_glob = None
+    if not m.direct:
+        d_glob = torch.zeros(B, 3 * C, device=d_feat.device, dtype=torch.float32)
+        for i, s in enumerate("rnt"):
+            ds, dfe = next(gi), next(gi)
+            dgi = _zeros_like_or(dfe, tape.d["head_" + s]["x"])
+            if ds is not None:
+                _head_backward(m, tape, s, ds.contiguous().float(), dgi)
+            d_glob[:, i * C:(i + 1) * C] = dgi
+    dtok = dgaf_backward(m, tape, d_feat, B)
+    dtokens = torch.empty(3 * B * L, C, device=d_feat.device, dtype=m.compute_dtype)
+    for i in range(3):
+        sl = slice(i * B * L, (i + 1) * B * L)
+        ops.tokens_grad(dtok[sl], d_glob, i * C, 3 * C, None, 0, 0, False, dtokens[sl], B, L)
+    trunk_backward(m, tape, dtokens)
+
+
+def dgaf_backward(m, tape, dout, B):
+    """-> dtok (3B*L, C) fp32: gradient w.r.t. the trunk's tokens through DGAF-V3 (cls rows zero).  Reverse of
+    hip_forward.dgaf_forward; parameter gradients are accumulated into the flat gradient buffer."""
+    g, P, G, t = m.geom, m.ptab, m.grad_buffer(), tape.d
+    L, C, nh = g.n_patches + 1, g.feat_dim, g.dgaf_heads
+    dh = C // nh
+    dev = dout.device
+    d = "dgaf."
+    tokens = t["tokens"]
+    T = tokens.dtype
+
+    def off(n):
+        return P.off(d + n)
+
+    def lin_bwd(dy, x, name, dx_out=None, accumulate=False):
+        """y = x W^T + b: dW += dy^T x, db += colsum(dy), returns dx = dy W (optionally accumulated into dx_out)."""
+        W = P.f(d + name + ".weight")
+        ops.gemm_tn(dy, x, G, out_off=off(name + ".weight"), ldc=W.shape[1], accumulate=True)
+        ops.colsum(dy, out=G[off(name + ".bias"):off(name + ".bias") + W.shape[0]], accumulate=True)
+        return ops.gemm(dy, W.t(), out=dx_out, accumulate=accumulate)
+
+    dout = dout.contiguous()
+    h, g1n, aux = t["dg_h"], t["dg_g1n"], t["dg_aux"]
+    alpha = P.f(d + "_alpha").view(1)
+    # out = h_s + enh ; enh = LN(modal_enhance.0(fused))
+    denh = ops.dgaf_sum3(dout, C)
+    mean2, rstd2 = t["dg_ln2"]
+    dm1 = ops.layernorm_bwd(denh, t["dg_m1"], P.f(d + "modal_enhance.1.weight"), mean2, rstd2, dw=G[off("modal_enhance.1.weight"):],
+                            db=G[off("modal_enhance.1.bias"):])
+    dfused = lin_bwd(dm1, t["dg_fused"], "modal_enhance.0")
+    # gates + blend
+    dhh, dE, dg1n, dlogit, dalpha = ops.dgaf_gate_fuse_bwd(dfused, dout, h, g1n, P.f(d + "gate_net.3.weight"), aux, alpha, g.dgaf_tau)
+    ops.gemm_tn(dlogit, t["dg_relu"], G, out_off=off("gate_net.3.weight"), ldc=C, accumulate=True)
+    ops.colsum(dlogit, out=G[off("gate_net.3.bias"):off("gate_net.3.bias") + 3], accumulate=True)
+    ops.colsum(dalpha.view(B, 1), out=G[off("_alpha"):off("_alpha") + 1], accumulate=True)
+    mean1, rstd1 = t["dg_ln1"]
+    dg1 = ops.layernorm_bwd(dg1n, t["dg_g1"], P.f(d + "gate_net.1.weight"), mean1, rstd1, dw=G[off("gate_net.1.weight"):],
+                            db=G[off("gate_net.1.bias"):])
+    lin_bwd(dg1, h.view(B, 3 * C), "gate_net.0", dx_out=dhh.view(B, 3 * C), accumulate=True)
+    lin_bwd(dE.view(3 * B, C), h, "entropy_proj", dx_out=dhh.view(3 * B, C), accumulate=True)
+    # attention pooling: LayerNorm <- out_proj <- per-head value projection <- pooled tokens
+    mean0, rstd0 = t["dg_ln"]
+    dao = ops.layernorm_bwd(dhh.view(3 * B, C), t["dg_ao"], P.f(d + "attn_norm.weight"), mean0, rstd0, dw=G[off("attn_norm.weight"):],
+                            db=G[off("attn_norm.bias"):])
+    do = lin_bwd(dao, t["dg_o"], "attn_pool.out_proj")                                          # (3B, C)
+    o_w, o_b = off("attn_pool.in_proj_weight"), off("attn_pool.in_proj_bias")
+    pooled = t["dg_pooled"]
+    # dWv[h*dh + m, n] += sum_(b,s) do[(b,s), h*dh + m] pooled[b,s,h,n]
+    ops.gemm_raw(do, pooled, G, dh, C, 3 * B, 1, C, 1, nh * C, C, c_off=o_w + 2 * C * C, batch1=nh, sA=(dh, 0), sB=(C, 0), sC=(dh * C, 0),
+                 accumulate=True)
+    ops.colsum(do, out=G[o_b + 2 * C:o_b + 3 * C], accumulate=True)
+    dpooled = torch.empty(B, 3, nh, C, device=dev, dtype=torch.float32)
+    ops.gemm_raw(do, P.flat, dpooled, 3 * B, C, dh, C, 1, 1, C, nh * C, b_off=o_w + 2 * C * C, batch1=nh, sA=(dh, 0), sB=(dh * C, 0), sC=(C, 0))
+    dS, dtok = ops.dgaf_attn_pool_bwd(dpooled, pooled, t["dg_probs"], tokens, B, L, C, nh, NC_PAD)
+    # scores S = tokens U^T
+    U = t["dg_U"]
+    if T == torch.bfloat16:
+        dS_lp = ops.cast_f32_bf16(dS.view(-1), torch.empty(dS.numel(), device=dev, dtype=torch.bfloat16)).view_as(dS)
+        Ut = ops.transpose(U)
+    else:
+        dS_lp, Ut = dS, U.t()
+    dU = torch.empty(NC_PAD, C, device=dev, dtype=torch.float32)
+    ops.gemm_tn(dS_lp, tokens, dU, accumulate=False)
+    ops.gemm(dS_lp, Ut, out=dtok, accumulate=True)
+    # U[s*nh + h, :] = dh^-0.5 Wk_h^T q3[s, h] ; q3 = Wq query + bq
+    q3 = t["dg_q3"]
+    scale = dh ** -0.5
+    dq3 = torch.empty(3, C, device=dev, dtype=torch.float32)
+    ops.gemm_raw(dU, P.flat, dq3, 1, dh, C, C, 1, C, 1, C, b_off=o_w + C * C, alpha=scale, batch1=3, batch2=nh, sA=(nh * C, C), sB=(0, dh * C),
+                 sC=(C, dh))
+    # dWk[h*dh + m, n] += scale * sum_s q3[s, h*dh + m] dU[s*nh + h, n]   (the three modalities share Wk: reduced inside one product)
+    ops.gemm_raw(q3, dU, G, dh, C, 3, 1, C, 1, nh * C, C, c_off=o_w + C * C, alpha=scale, batch1=nh, sA=(dh, 0), sB=(C, 0), sC=(dh * C, 0),
+                 accumulate=True)
+    s_q = P.stride(d + "rgb_query", d + "nir_query", d + "tir_query")
+    o_q = off("rgb_query")
+    # dWq[m, n] += sum_s dq3[s, m] query_s[n] ; dbq += colsum(dq3) ; dquery_s = dq3[s] Wq
+    ops.gemm_raw(dq3, P.flat, G, C, C, 3, 1, C, 1, s_q, C, b_off=o_q, c_off=o_w, accumulate=True)
+    ops.colsum(dq3, out=G[o_b:o_b + C], accumulate=True)
+    ops.gemm_raw(dq3, P.flat, G, 3, C, C, C, 1, 1, C, s_q, b_off=o_w, c_off=o_q, accumulate=True)
+    return dtok
+
+
 def _model_backward(m, tape, gouts):
+    if m.USE_DGAF:
+        return _model_backward_dgaf(m, tape, gouts)
     g = m.geom
     B, C = tape.d["B"], g.feat_dim
     gi = iter(gouts)

@@ -178,6 +178,64 @@ def hdm_forward(m, tokens: Tensor, ori: Tensor, B: int, training: bool, tape: Op
     return feats
 
 
+def cls_globals(m, tokens: Tensor, B: int) -> Tensor:
+    """(B, 3C) fp32 = [RGB_global | NI_global | TI_global], the trunk's cls rows (meta_arch.py:91-103)."""
+    g = m.geom
+    L, C = g.n_patches + 1, g.feat_dim
+    out = torch.empty(B, 3 * C, device=tokens.device, dtype=torch.float32)
+    for i in range(3):
+        ops.get_token0(tokens[i * B * L:(i + 1) * B * L], out, i * C, 3 * C, B, L)
+    return out
+
+
+def dgaf_forward(m, tokens: Tensor, B: int, tape: Optional[Tape] = None) -> Tensor:
+    """DGAF-V3 (dual_gated_fusion.py:661-745) on the patch tokens of the three modalities -> (B, 3C) fp32.
+    Attention pooling in the folded single-query form (csrc/dgaf.hip): q = Wq query + bq is batch independent, so the K/V
+    projections of the 3*B*128 tokens collapse into one skinny score GEMM against 3*heads folded keys and a per-head value
+    projection of the POOLED token."""
+    g = m.geom
+    L, C, nh = g.n_patches + 1, g.feat_dim, g.dgaf_heads
+    dh = C // nh
+    P = m.ptab
+    dev = tokens.device
+    T = tokens.dtype
+    d = "dgaf."
+    sv = tape is not None
+    s_q = P.stride(d + "rgb_query", d + "nir_query", d + "tir_query")
+    o_w, o_b = P.off(d + "attn_pool.in_proj_weight"), P.off(d + "attn_pool.in_proj_bias")
+    # q3[s] = Wq query_s + bq
+    q3 = torch.empty(3, C, device=dev, dtype=torch.float32)
+    ops.gemm_raw(P.flat, P.flat, q3, 3, C, C, s_q, 1, C, 1, C, a_off=P.off(d + "rgb_query"), b_off=o_w, bias=P.flat, bias_off=o_b)
+    # folded keys U[s*nh + h, :] = dh^-0.5 * Wk_h^T q3[s, h]  (zero padded to the MFMA kernel's N granule)
+    U = m.workspace("dgaf_U", (NC_PAD, C), T, zero=True)
+    ops.gemm_raw(q3, P.flat, U, 1, C, dh, C, 1, 1, C, C, b_off=o_w + C * C, alpha=dh ** -0.5, batch1=3, batch2=nh, sA=(C, dh),
+                 sB=(0, dh * C), sC=(nh * C, C))
+    S = ops.gemm(tokens, U, out_dtype=torch.float32)                              # (3B*L, NC_PAD)
+    pooled, probs = ops.dgaf_attn_pool(S, tokens, B, L, C, nh, NC_PAD, save_probs=sv)
+    # per-head value projection o[(b,s), h*dh + e] = Wv_h pooled[b,s,h,:] + bv
+    o = torch.empty(3 * B, C, device=dev, dtype=torch.float32)
+    ops.gemm_raw(pooled, P.flat, o, 3 * B, dh, C, nh * C, 1, C, 1, C, b_off=o_w + 2 * C * C, bias=P.flat, bias_off=o_b + 2 * C,
+                 batch1=nh, sA=(C, 0), sB=(dh * C, 0), sC=(dh, 0), sBias=(dh, 0))
+    ao = ops.gemm(o, P.f(d + "attn_pool.out_proj.weight"), bias=P.f(d + "attn_pool.out_proj.bias"))
+    r = ops.layernorm_fwd(ao, P.f(d + "attn_norm.weight"), P.f(d + "attn_norm.bias"), 1e-5, torch.float32, save=sv)
+    h = r[0] if sv else r                                                          # (3B, C) == (B, 3, C)
+    E = ops.gemm(h, P.f(d + "entropy_proj.weight"), bias=P.f(d + "entropy_proj.bias"))
+    g1 = ops.gemm(h.view(B, 3 * C), P.f(d + "gate_net.0.weight"), bias=P.f(d + "gate_net.0.bias"))
+    r1 = ops.layernorm_fwd(g1, P.f(d + "gate_net.1.weight"), P.f(d + "gate_net.1.bias"), 1e-5, torch.float32, save=sv)
+    g1n = r1[0] if sv else r1
+    alpha = P.f(d + "_alpha").view(1)
+    gf = ops.dgaf_gate_fuse(h, E, g1n, P.f(d + "gate_net.3.weight"), P.f(d + "gate_net.3.bias"), alpha, g.dgaf_tau, save=sv)
+    fused = gf[0] if sv else gf
+    m1 = ops.gemm(fused, P.f(d + "modal_enhance.0.weight"), bias=P.f(d + "modal_enhance.0.bias"))
+    r2 = ops.layernorm_fwd(m1, P.f(d + "modal_enhance.1.weight"), P.f(d + "modal_enhance.1.bias"), 1e-5, torch.float32, save=sv)
+    enh = r2[0] if sv else r2
+    out = ops.dgaf_combine(h, enh)
+    if sv:
+        tape.d.update(tokens=tokens, dg_q3=q3, dg_U=U, dg_probs=probs, dg_pooled=pooled, dg_o=o, dg_ao=ao, dg_ln=r[1:], dg_h=h,
+                      dg_g1=g1, dg_ln1=r1[1:], dg_g1n=g1n, dg_relu=gf[1], dg_aux=gf[2], dg_fused=fused, dg_m1=m1, dg_ln2=r2[1:])
+    return out
+
+
 def atmoe_forward(m, feats: Tensor, B: int, training: bool, tape: Optional[Tape] = None) -> Tensor:
     """ATMoE (AttnMOE.py:94-121): attention gate over the 7 features + 7*H per-chunk experts -> (B, 7C) fp32."""
     g = m.geom

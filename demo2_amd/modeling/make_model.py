@@ -30,6 +30,7 @@ from .._lib import DemoHipError
 from . import hip_forward as HF
 from .backbones.vit_pytorch import _Holder, vit_base_patch16_224
 from .meta_arch import build_transformer, weights_init_classifier, weights_init_kaiming
+from .dual_gated_fusion import DualGatedAdaptiveFusionV3
 from .moe.AttnMOE import GeneralFusion, QuickGELU
 
 ALIGN = 64  # elements; keeps every parameter 256-B aligned in the fp32 buffer (128 B in the bf16 shadow)
@@ -89,10 +90,20 @@ def _layout(named) -> tuple:
 class DeMo(_Holder):
     def __init__(self, num_classes, cfg, camera_num, view_num, factory):
         super().__init__()
-        for flag in ("USE_SACR", "USE_SDTPS", "USE_LIF", "USE_DGAF", "USE_MULTIMODAL_SACR"):
+        for flag in ("USE_SACR", "USE_SDTPS", "USE_LIF", "USE_MULTIMODAL_SACR"):
             if getattr(cfg.MODEL, flag, False):
                 raise NotImplementedError(f"MODEL.{flag}: alternative fusion modules are outside the PIFE->HDM->ATMoE hot path "
                                           "(SURVEY.md section 2, rows 5/13/14)")
+        if getattr(cfg.MODEL, "USE_FRCA", None) is True:
+            raise NotImplementedError("MODEL.USE_FRCA: the Fourier channel-attention selector is outside the hot path")
+        # the `DeMo` class's DGAF-only branch (make_model.py:835-865) with DGAF_VERSION 'v3'
+        self.USE_DGAF = bool(getattr(cfg.MODEL, "USE_DGAF", False))
+        if self.USE_DGAF:
+            if getattr(cfg.MODEL, "DGAF_VERSION", "v3") != "v3":
+                raise NotImplementedError("MODEL.DGAF_VERSION: only 'v3' (attention pooling on the patch tokens) is built")
+            if cfg.MODEL.HDM or cfg.MODEL.ATM:
+                raise NotImplementedError("USE_DGAF together with HDM/ATM has no defined forward in the reference "
+                                          "(its DeMo class dropped HDM/ATM, make_model.py:450-461)")
         if 'vit_base_patch16_224' in cfg.MODEL.TRANSFORMER_TYPE:
             self.feat_dim = getattr(cfg.MODEL, 'TRUNK_WIDTH', 768)
         elif 'ViT-B-16' in cfg.MODEL.TRANSFORMER_TYPE:
@@ -123,6 +134,14 @@ class DeMo(_Holder):
             self.bottleneck_moe = nn.BatchNorm1d(7 * C)
             self.bottleneck_moe.bias.requires_grad_(False)
             self.bottleneck_moe.apply(weights_init_kaiming)
+        if self.USE_DGAF:                                                # make_model.py:592-634
+            self.dgaf = DualGatedAdaptiveFusionV3(feat_dim=C, output_dim=3 * C, tau=cfg.MODEL.DGAF_TAU, init_alpha=cfg.MODEL.DGAF_INIT_ALPHA,
+                                                  num_heads=cfg.MODEL.DGAF_NUM_HEADS)
+            self.classifier_dgaf = nn.Linear(3 * C, num_classes, bias=False)
+            self.classifier_dgaf.apply(weights_init_classifier)
+            self.bottleneck_dgaf = nn.BatchNorm1d(3 * C)
+            self.bottleneck_dgaf.bias.requires_grad_(False)
+            self.bottleneck_dgaf.apply(weights_init_kaiming)
         if self.direct:                                                  # make_model.py:174-179
             self.classifier = nn.Linear(3 * C, num_classes, bias=False)
             self.classifier.apply(weights_init_classifier)
@@ -169,6 +188,8 @@ class DeMo(_Holder):
         g.feat_dim, g.moe_head, g.hdm_heads = self.feat_dim, self.head, self.feat_dim // 64
         g.global_local = bool(self.GLOBAL_LOCAL)
         g.hdm_dropout = 0.1
+        g.dgaf_heads = int(getattr(cfg.MODEL, "DGAF_NUM_HEADS", 8))
+        g.dgaf_tau = float(getattr(cfg.MODEL, "DGAF_TAU", 1.0))
         g.bn_eps, g.bn_momentum = 1e-5, 0.1
         g.sie_coe = float(cfg.MODEL.SIE_COE)
         p = "BACKBONE.base."
@@ -410,6 +431,11 @@ class DeMo(_Holder):
         training = self.training if training is None else training
         B = imgs[0].shape[0]
         tokens = HF.trunk_forward(self, imgs, cam, self.compute_dtype, zero_mod)
+        if self.USE_DGAF:                                                # class DeMo, DGAF-only branch (make_model.py:835-865)
+            feat = HF.dgaf_forward(self, tokens, B)
+            if not training:
+                return feat
+            return self._train_outputs_dgaf(feat, HF.cls_globals(self, tokens, B), None)
         ori = HF.pife_forward(self, tokens, B)
         moe = None
         if self.HDM:
@@ -422,6 +448,17 @@ class DeMo(_Holder):
         if return_pattern == 2:
             return moe
         return torch.cat([ori, moe], dim=-1)
+
+    def _train_outputs_dgaf(self, feat, globs, tape):
+        """(dgaf_score, dgaf_feat) [+ per-modality (score, global) pairs when DIRECT = 0]  (make_model.py:853-862)"""
+        C = self.feat_dim
+        out = (HF.head_forward(self, feat, "bottleneck_dgaf", "classifier_dgaf", True, tape, "dgaf"), feat)
+        if not self.direct:
+            for i, s in enumerate("rnt"):
+                gi = globs[:, i * C:(i + 1) * C].contiguous()
+                out += (HF.head_forward(self, gi, "bottleneck_" + s, "classifier_" + s, True, tape, s), gi)
+        self._nbt_flat += 1
+        return out
 
     def _train_outputs(self, ori, moe, tape):
         C = self.feat_dim

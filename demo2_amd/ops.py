@@ -384,6 +384,88 @@ def atmoe_gate_softmax_bwd(dgates: Tensor, gates: Tensor, q: Tensor, k: Tensor, 
     return dq, dk
 
 
+# ------------------------------------------------------------------------------------------------
+# DGAF-V3 (dual_gated_fusion.py:558-745)
+# ------------------------------------------------------------------------------------------------
+def dgaf_attn_pool(S: Tensor, tokens: Tensor, Bs: int, L: int, Cd: int, nh: int, ldS: int, save_probs: bool = False):
+    """-> pooled (Bs,3,nh,C) fp32, probs (Bs,3,nh,L-1) fp32 or None"""
+    _req_cuda(S, tokens)
+    assert S.dtype == torch.float32 and S.is_contiguous() and S.shape == (3 * Bs * L, ldS)
+    assert tokens.is_contiguous() and tokens.shape == (3 * Bs * L, Cd)
+    pooled = torch.empty(Bs, 3, nh, Cd, device=S.device, dtype=torch.float32)
+    probs = torch.empty(Bs, 3, nh, L - 1, device=S.device, dtype=torch.float32) if save_probs else None
+    check(_lib.load().demo_dgaf_attn_pool(S.data_ptr(), ldS, tokens.data_ptr(), dt_code(tokens.dtype), pooled.data_ptr(), _ptr(probs), Bs, L, Cd,
+                                          nh, _stream()), "demo_dgaf_attn_pool")
+    return pooled, probs
+
+
+def dgaf_attn_pool_bwd(dpooled: Tensor, pooled: Tensor, probs: Tensor, tokens: Tensor, Bs: int, L: int, Cd: int, nh: int, ldS: int):
+    """-> dS (3*Bs*L, ldS) fp32, dtokens (3*Bs*L, C) fp32 (both fully written)"""
+    _req_cuda(dpooled, pooled, probs, tokens)
+    for t, shp in ((dpooled, (Bs, 3, nh, Cd)), (pooled, (Bs, 3, nh, Cd)), (probs, (Bs, 3, nh, L - 1))):
+        assert t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shp, (t.shape, shp)
+    assert tokens.is_contiguous() and tokens.shape == (3 * Bs * L, Cd)
+    dS = torch.empty(3 * Bs * L, ldS, device=tokens.device, dtype=torch.float32)
+    dtok = torch.empty(3 * Bs * L, Cd, device=tokens.device, dtype=torch.float32)
+    check(_lib.load().demo_dgaf_attn_pool_bwd(dpooled.data_ptr(), pooled.data_ptr(), probs.data_ptr(), tokens.data_ptr(), dt_code(tokens.dtype),
+                                              dS.data_ptr(), ldS, dtok.data_ptr(), Bs, L, Cd, nh, _stream()), "demo_dgaf_attn_pool_bwd")
+    return dS, dtok
+
+
+def dgaf_gate_fuse(h: Tensor, E: Tensor, g1n: Tensor, W2: Tensor, b2: Tensor, alpha_raw: Tensor, tau: float, save: bool = False):
+    """h, E (Bs,3,C) ; g1n (Bs,C) -> fused (Bs,C) [, relu(g1n) (Bs,C), aux (Bs,16) when save]"""
+    _req_cuda(h, E, g1n, W2, b2, alpha_raw)
+    Bs, Cd = g1n.shape
+    for t, n in ((h, 3 * Bs * Cd), (E, 3 * Bs * Cd), (g1n, Bs * Cd), (W2, 3 * Cd), (b2, 3), (alpha_raw, 1)):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n
+    fused = torch.empty(Bs, Cd, device=h.device, dtype=torch.float32)
+    relu = torch.empty(Bs, Cd, device=h.device, dtype=torch.float32) if save else None
+    aux = torch.empty(Bs, 16, device=h.device, dtype=torch.float32) if save else None
+    check(_lib.load().demo_dgaf_gate_fuse(h.data_ptr(), E.data_ptr(), g1n.data_ptr(), W2.data_ptr(), b2.data_ptr(), alpha_raw.data_ptr(),
+                                          float(tau), fused.data_ptr(), _ptr(relu), _ptr(aux), Bs, Cd, _stream()), "demo_dgaf_gate_fuse")
+    return (fused, relu, aux) if save else fused
+
+
+def dgaf_gate_fuse_bwd(dfused: Tensor, dres: Optional[Tensor], h: Tensor, g1n: Tensor, W2: Tensor, aux: Tensor, alpha_raw: Tensor, tau: float):
+    """-> dh (Bs,3,C), dE (Bs,3,C), dg1n (Bs,C), dlogit (Bs,3), dalpha (Bs)"""
+    _req_cuda(dfused, dres, h, g1n, W2, aux, alpha_raw)
+    Bs, Cd = g1n.shape
+    for t, n in ((dfused, Bs * Cd), (h, 3 * Bs * Cd), (g1n, Bs * Cd), (W2, 3 * Cd), (aux, 16 * Bs), (alpha_raw, 1)):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n
+    if dres is not None:
+        assert dres.dtype == torch.float32 and dres.is_contiguous() and dres.numel() == 3 * Bs * Cd
+    dev = h.device
+    dh = torch.empty(Bs, 3, Cd, device=dev, dtype=torch.float32)
+    dE = torch.empty(Bs, 3, Cd, device=dev, dtype=torch.float32)
+    dg1n = torch.empty(Bs, Cd, device=dev, dtype=torch.float32)
+    dlogit = torch.empty(Bs, 3, device=dev, dtype=torch.float32)
+    dalpha = torch.empty(Bs, device=dev, dtype=torch.float32)
+    check(_lib.load().demo_dgaf_gate_fuse_bwd(dfused.data_ptr(), _ptr(dres), h.data_ptr(), g1n.data_ptr(), W2.data_ptr(), aux.data_ptr(),
+                                              alpha_raw.data_ptr(), float(tau), dh.data_ptr(), dE.data_ptr(), dg1n.data_ptr(), dlogit.data_ptr(),
+                                              dalpha.data_ptr(), Bs, Cd, _stream()), "demo_dgaf_gate_fuse_bwd")
+    return dh, dE, dg1n, dlogit, dalpha
+
+
+def dgaf_combine(h: Tensor, enh: Tensor) -> Tensor:
+    """out (Bs, 3C): out[b, s*C + c] = h[b,s,c] + enh[b,c]"""
+    _req_cuda(h, enh)
+    Bs, Cd = enh.shape
+    assert h.dtype == torch.float32 and enh.dtype == torch.float32 and h.is_contiguous() and enh.is_contiguous() and h.numel() == 3 * Bs * Cd
+    out = torch.empty(Bs, 3 * Cd, device=h.device, dtype=torch.float32)
+    check(_lib.load().demo_dgaf_combine(h.data_ptr(), enh.data_ptr(), out.data_ptr(), Bs, Cd, _stream()), "demo_dgaf_combine")
+    return out
+
+
+def dgaf_sum3(dout: Tensor, Cd: int) -> Tensor:
+    """denh (Bs, C) = sum_s dout[:, s*C:(s+1)*C]"""
+    _req_cuda(dout)
+    Bs = dout.shape[0]
+    assert dout.dtype == torch.float32 and dout.is_contiguous() and dout.shape == (Bs, 3 * Cd)
+    denh = torch.empty(Bs, Cd, device=dout.device, dtype=torch.float32)
+    check(_lib.load().demo_dgaf_sum3(dout.data_ptr(), denh.data_ptr(), Bs, Cd, _stream()), "demo_dgaf_sum3")
+    return denh
+
+
 def gemm_tn(a: Tensor, b: Tensor, out: Tensor, out_off: int = 0, ldc: Optional[int] = None, alpha: float = 1.0, accumulate: bool = True,
             colsum_out: Optional[Tensor] = None, colsum_off: int = 0):
     """out_flat[out_off + m*ldc + n] (+)= alpha * sum_r a[r, m] * b[r, n]   (weight gradients: a = dY, b = X).

@@ -172,6 +172,34 @@ int demo_atmoe_gate_softmax(const float* q, const float* k, float* gates, int32_
 int demo_atmoe_gate_softmax_bwd(const float* dgates, const float* gates, const float* q, const float* k, float* dq, float* dk,
                                 int32_t Bs, int32_t C, int32_t H, void* stream);
 
+/* ---- DGAF-V3 (modeling/dual_gated_fusion.py:558-745: attention pooling :661-679, IEG :681-719, MIG :721-730, blend :732-745),
+ * the fusion head of the reference's `DeMo` class with MODEL.USE_DGAF (make_model.py:835-865) -------------------------------- */
+/* Attention pooling in the folded single-query form.  S (3*Bs*L, ldS) fp32 from demo_gemm against the folded keys: column
+ * s*nh + h of the rows of modality s = score of head h.  For sample b, modality s, head h: softmax over the L-1 PATCH tokens
+ * (row 0 of an image, the cls token, is not part of DGAF's input), pooled[b,s,h,:] = sum_n p_n tokens_n -> fp32 (Bs,3,nh,C);
+ * probs (optional, (Bs,3,nh,L-1)) kept for the backward. */
+int demo_dgaf_attn_pool(const float* S, int64_t ldS, const void* tokens, int32_t dt, float* pooled, float* probs, int32_t Bs,
+                        int32_t L, int32_t C, int32_t nh, void* stream);
+/* Backward of the above: dS (3*Bs*L, ldS) and dtokens (3*Bs*L, C), both fp32, are fully written (zeros outside a modality's
+ * own columns and on the cls rows). */
+int demo_dgaf_attn_pool_bwd(const float* dpooled, const float* pooled, const float* probs, const void* tokens, int32_t dt,
+                            float* dS, int64_t ldS, float* dtokens, int32_t Bs, int32_t L, int32_t C, int32_t nh, void* stream);
+/* Both gates and the blend for one sample per workgroup.  h (Bs,3,C) pooled + LayerNormed modality features, E (Bs,3,C) =
+ * entropy_proj(h), g1n (Bs,C) = LayerNorm(gate_net.0(cat h)) before the ReLU, W2 (3,C) / b2 (3) = gate_net.3, alpha_raw = _alpha.
+ * fused (Bs,C) = a * sum_s softmax_s(mean(E_s) exp(-H(h_s)/tau)) h_s + (1-a) * sum_s sigmoid(W2_s . relu(g1n) + b2_s) h_s, a = sigmoid(_alpha).
+ * relu_out (optional, (Bs,C)) = relu(g1n); aux (optional, (Bs,16)) = {ew[3], gate[3], H[3], z[3], sum|h|[3]} for the backward. */
+int demo_dgaf_gate_fuse(const float* h, const float* E, const float* g1n, const float* W2, const float* b2, const float* alpha_raw,
+                        float tau, float* fused, float* relu_out, float* aux, int32_t Bs, int32_t C, void* stream);
+/* Backward: dh (Bs,3,C) = dres (optional, gradient reaching h directly) + blend + entropy paths; dE (Bs,3,C); dg1n (Bs,C);
+ * dlogit (Bs,3) = gradient of gate_net.3's output before the sigmoid (its weight/bias gradients are the caller's GEMMs);
+ * dalpha (Bs) = per-sample gradient of _alpha. */
+int demo_dgaf_gate_fuse_bwd(const float* dfused, const float* dres, const float* h, const float* g1n, const float* W2,
+                            const float* aux, const float* alpha_raw, float tau, float* dh, float* dE, float* dg1n, float* dlogit,
+                            float* dalpha, int32_t Bs, int32_t C, void* stream);
+/* out[b, s*C + c] = h[b,s,c] + enh[b,c]  (:739-745) and the enhancement's gradient denh[b,c] = sum_s dout[b, s*C + c] */
+int demo_dgaf_combine(const float* h, const float* enh, float* out, int32_t Bs, int32_t C, void* stream);
+int demo_dgaf_sum3(const float* dout, float* denh, int32_t Bs, int32_t C, void* stream);
+
 /* ---- backward-only entry points ------------------------------------------------------------------------- */
 /* Weight-gradient GEMM, both operands reduction-major (rows = tokens, exactly as the forward left them):
  * C[Mo,No] (+)= alpha * sum_r A[r,Mo] * B[r,No]; bf16 MFMA, split over the reduction with fp32 atomics.

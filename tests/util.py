@@ -43,7 +43,8 @@ def spec_of(model) -> O.Spec:
                   width=g.width, layers=g.layers, heads=g.heads, feat_dim=g.feat_dim, moe_head=g.moe_head,
                   num_classes=model.num_classes, camera_num=model.camera, sie_camera=bool(c.MODEL.SIE_CAMERA),
                   sie_coe=g.sie_coe, global_local=g.global_local, hdm=bool(model.HDM), atm=bool(model.ATM),
-                  direct=int(model.direct), miss=c.TEST.MISS)
+                  direct=int(model.direct), miss=c.TEST.MISS, use_dgaf=bool(getattr(model, "USE_DGAF", False)),
+                  dgaf_heads=g.dgaf_heads, dgaf_tau=g.dgaf_tau)
 
 
 def synth_batch(B, h, w, cams, seed=1234, device="cpu"):
