@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="replay the training step from a captured hipGraph (single GPU); measured equal to eager launches")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--fusion", choices=["atmoe", "dgaf"], default="atmoe",
+                    help="atmoe: the headline PIFE -> HDM -> ATMoE model; dgaf: the DeMo class's DGAF-V3 head (SURVEY 8(f) row 3, a side "
+                         "measurement, not BASELINE.json's metric)")
     ap.add_argument("--host-input", action="store_true",
                     help="train mode: copy each batch from pinned host memory (double-buffered side stream); PCIe-inclusive rate")
     return ap.parse_args()
@@ -125,13 +128,13 @@ def gemm_roofline(model, step_fn):
     return out
 
 
-def cpu_baseline(mode, seconds):
+def cpu_baseline(mode, seconds, fusion="atmoe"):
     """The CPU restatement (oracle) on this host's cores, bounded sample of the same workload (B=2 batches)."""
     from oracle import demo_oracle as O
     from util import synth_batch
     # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
-    spec = O.Spec()
+    spec = O.Spec() if fusion == "atmoe" else O.Spec(hdm=False, atm=False, use_dgaf=True)
     sd = O.init_state_dict(spec, seed=1)
     x, cam = synth_batch(2, 256, 128, 4)
     target = torch.tensor([0, 0])
@@ -154,7 +157,7 @@ def cpu_baseline(mode, seconds):
         if dt >= seconds and n >= 2:
             break
     return {"value": round(2 * n / dt, 2), "unit": "triplets/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} {'fwd+bwd' if mode == 'train' else 'eval forward'} passes of the fp32 CPU oracle, RGBNT201 DeMo config, B=2 "
+            "sample": f"{n} {'fwd+bwd' if mode == 'train' else 'eval forward'} passes of the fp32 CPU oracle, RGBNT201 " + ("DeMo" if fusion == "atmoe" else "DGAF-V3") + f" config, B=2 "
                       f"({dt:.1f} s)"}
 
 
@@ -181,12 +184,12 @@ def main():
     dev = torch.device("cuda", local)
     mode = a.mode if a.mode != "auto" else ("train" if have_backward() else "fwd")
     B = a.batch or (128 if mode == "train" else 64)
-    B_TRAFFIC_VALID[0] = mode == "train" and B == 128 and a.dtype == "bf16"
+    B_TRAFFIC_VALID[0] = mode == "train" and B == 128 and a.dtype == "bf16" and a.fusion == "atmoe"
 
     from demo2_amd.modeling import make_model
     from oracle import demo_oracle as O      # only for the seeded weight factory + cpu_baseline (checker side)
     from util import make_cfg, spec_of, synth_batch
-    cfg = make_cfg("RGBNT201")
+    cfg = make_cfg("RGBNT201") if a.fusion == "atmoe" else make_cfg("RGBNT201", HDM=False, ATM=False, USE_DGAF=True)
     torch.manual_seed(1234)
     model = make_model(cfg, 171, 4, 0)
     model.load_state_dict(O.init_state_dict(spec_of(model), seed=1))
@@ -276,17 +279,19 @@ def main():
             model.grad_sync = saved_sync
         log("roofline pass done; cpu baseline next")
         if world == 1 and not a.no_cpu_baseline:
-            cpu = cpu_baseline(mode, a.cpu_seconds)
+            cpu = cpu_baseline(mode, a.cpu_seconds, a.fusion)
     if rank == 0:
         ms = dt / a.steps * 1e3
         val = B * world * a.steps / dt
-        flop_per_triplet = 69.99e9 * (3 if mode == "train" else 1)
+        # SURVEY.md 8(d), config A (HDM counted unfolded, as the survey does); DGAF head: trunk 68.34 G + 0.05 G folded fusion
+        flop_per_triplet = (69.99e9 if a.fusion == "atmoe" else 68.39e9) * (3 if mode == "train" else 1)
         line = {
             "metric": "tri-modal images/sec " + ("fwd+bwd" if mode == "train" else "fwd"),
             "value": round(val, 1), "unit": "triplets/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": ("RGBNT201 DeMo.yml (CLIP ViT-B/16 x3 + PIFE + HDM + ATMoE), "
+            "config": {"workload": (("RGBNT201 DeMo.yml (CLIP ViT-B/16 x3 + PIFE + HDM + ATMoE), " if a.fusion == "atmoe" else
+                                     "RGBNT201 geometry, DeMo class with MODEL.USE_DGAF (CLIP ViT-B/16 x3 + DGAF-V3), ")
                                     + ("train step fwd+bwd, " if mode == "train" else "eval forward, ")
                                     + f"3x({B},3,256,128) per GPU, random-init weights"),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "mode": mode,

@@ -130,3 +130,24 @@ def test_evaluator_host_aggregation_matches_oracle(monkeypatch):
     cmc_ref, map_ref = O.eval_market1501(dist, q_pids, g_pids, q_cam, g_cam, 20)
     np.testing.assert_allclose(cmc, cmc_ref, atol=1e-7)
     assert abs(mAP - map_ref) < 1e-12
+
+
+def test_dgaf_state_dict_matches_reference_fixture(golden):
+    """MODEL.USE_DGAF builds the reference's DualGatedAdaptiveFusionV3 keys and shapes (fixture = the reference module's own
+    state_dict, C=64 / 4 heads) plus classifier_dgaf / bottleneck_dgaf (make_model.py:630-634); combinations the reference
+    does not define stay loud."""
+    g = golden("dgaf_v3_c64_h4")
+    c = small_cfg(HDM=False, ATM=False, USE_DGAF=True, DGAF_NUM_HEADS=4, TRUNK_OUT_DIM=64)
+    m = make_model(c, 11, 3, 0)
+    got = m.dgaf.state_dict()
+    assert set(got) == set(g["sd"])
+    assert all(tuple(got[k].shape) == tuple(g["sd"][k].shape) for k in got)
+    assert tuple(m.classifier_dgaf.weight.shape) == (11, 192) and m.bottleneck_dgaf.bias.requires_grad is False
+    want = O.init_state_dict(spec_of(m))
+    assert set(m.state_dict()) == set(want)
+    with pytest.raises(NotImplementedError):
+        make_model(small_cfg(USE_DGAF=True), 11, 3, 0)                         # together with HDM/ATM: undefined in the reference
+    with pytest.raises(NotImplementedError):
+        make_model(small_cfg(HDM=False, ATM=False, USE_DGAF=True, DGAF_VERSION="v1"), 11, 3, 0)
+    with pytest.raises(NotImplementedError):
+        make_model(small_cfg(USE_FRCA=True), 11, 3, 0)
