@@ -14,6 +14,11 @@ extern "C" int demo_gemm_path(const demo_gemm_desc* d) {
   if (!d || !demo_gemm_bf16_eligible(*d)) return 0;
   return demo_gemm_bf16_config(*d) == 2566 ? 2 : 1;
 }
+int demo_gemm_bf16_split_rows(const demo_gemm_desc& d);
+extern "C" int demo_gemm_split_rows(const demo_gemm_desc* d) {
+  if (!d || !demo_gemm_bf16_eligible(*d)) return 0;
+  return demo_gemm_bf16_split_rows(*d);
+}
 extern "C" int demo_gemm_desc_size(void) { return (int)sizeof(demo_gemm_desc); }
 
 extern "C" int demo_gemm(const demo_gemm_desc* dp, void* stream) {

@@ -731,7 +731,43 @@ int demo_gemm_bf16_config(const demo_gemm_desc& d) {
   return cfg;
 }
 
+// Row split of a 256^2 launch whose tile count leaves a small last round (582 tiles on 256 CUs = 2.27 rounds at N = 768,
+// M = 49536: a third round running 27 % full): the rows that fill whole rounds go to the 256^2 kernel, the rest to the 128^2
+// kernel, whose 4x smaller tiles at 2 workgroups/CU cover them in one short round.  Returns the rows of the first part
+// (a multiple of 256), 0 = no split.  g_split_left: largest leftover (in 256^2 tiles) that is split off; 0 disables.
+static int g_split_left = 128;
+extern "C" int demo_gemm_set_split(int max_left_tiles) { g_split_left = max_left_tiles; return 0; }
+int demo_gemm_bf16_split_rows(const demo_gemm_desc& d) {
+  if (g_force_tile != 0 || g_split_left <= 0 || d.batch1 * d.batch2 != 1) return 0;
+  if (demo_gemm_bf16_config(d) != 2566) return 0;
+  const int64_t ntm = cdiv64(d.M, 256), ntn = d.N / 256, total = ntm * ntn;
+  const int64_t full = total / 256, left = total - full * 256;
+  if (full < 1 || left == 0 || left > g_split_left) return 0;
+  const int64_t tm1 = full * 256 / ntn;
+  if (tm1 < 1 || tm1 * 256 >= d.M) return 0;
+  return (int)(tm1 * 256);
+}
+
 int demo_gemm_bf16(const demo_gemm_desc& d, hipStream_t s) {
+  const int m1 = demo_gemm_bf16_split_rows(d);
+  if (m1 > 0) {
+    demo_gemm_desc a = d, b = d;
+    a.M = m1;
+    b.M = d.M - m1;
+    const int64_t szC = d.dtC == DEMO_F32 ? 4 : 2, szP = d.dtPre == DEMO_F32 ? 4 : 2;
+    b.A = (const char*)d.A + (int64_t)m1 * d.a_rs * 2;
+    b.C = (char*)d.C + (int64_t)m1 * d.c_rs * szC;
+    if (d.residual) b.residual = d.residual + (int64_t)m1 * d.c_rs;
+    if (d.act_grad_pre) b.act_grad_pre = (const char*)d.act_grad_pre + (int64_t)m1 * d.c_rs * szP;
+    if (d.pre_out) b.pre_out = (char*)d.pre_out + (int64_t)m1 * d.c_rs * szC;
+    const int saved = g_force_tile;
+    g_force_tile = 2566;
+    int rc = demo_gemm_bf16(a, s);
+    g_force_tile = 1282;
+    if (rc == 0) rc = demo_gemm_bf16(b, s);
+    g_force_tile = saved;
+    return rc;
+  }
   FArgs p;
   p.A = reinterpret_cast<const bf16_t*>(d.A);
   p.B = reinterpret_cast<const bf16_t*>(d.B);

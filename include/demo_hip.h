@@ -67,6 +67,11 @@ int demo_gemm(const demo_gemm_desc* d, void* stream);
 /* what demo_gemm would pick: 0 = generic fp32-FMA kernel, 1 = bf16 MFMA 128x128 kernel, 2 = bf16 MFMA 256x256 ping-pong kernel */
 int demo_gemm_path(const demo_gemm_desc* d);
 int demo_gemm_force_tile(int tile); /* tuning hook: 128 / 256 forces that MFMA tile configuration, 0 = heuristic; returns 0 */
+/* A 256x256 launch whose tile count leaves a small last round is issued as two launches: rows [0, r) on the 256x256 kernel
+ * (whole rounds of the 256 CUs) and rows [r, M) on the 128x128 kernel.  demo_gemm_split_rows: the r demo_gemm would use
+ * (0 = one launch); demo_gemm_set_split: largest leftover, in 256x256 tiles, that is split off (default 128, 0 = never). */
+int demo_gemm_split_rows(const demo_gemm_desc* d);
+int demo_gemm_set_split(int max_left_tiles);
 int demo_gemm_desc_size(void); /* sizeof(demo_gemm_desc): lets a foreign binding verify its struct layout */
 
 /* ---- elementwise / layout ----------------------------------------------------------------- */
