@@ -1,0 +1,184 @@
+"""CPU: the data-side contract -- P x K samplers, their data-parallel form over gloo (world size 2), the
+collate layout and the device feeder -- against the properties the reference's loaders guarantee, and against the reference's
+own samplers where /root/reference is mounted (build container only)."""
+import importlib.util
+import os
+import socket
+import sys
+from collections import Counter
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from demo2_amd.data import DeviceFeeder, RandomIdentitySampler, RandomIdentitySampler_DDP, train_collate_fn, val_collate_fn
+
+REF = os.environ.get("DEMO_REFERENCE", "/root/reference")
+
+
+def source(n_ids=37, seed=0, lo=1, hi=11):
+    rng = np.random.RandomState(seed)
+    src = []
+    for pid in range(n_ids):
+        for _ in range(rng.randint(lo, hi)):
+            src.append((f"img_{len(src)}.jpg", pid, int(rng.randint(0, 4)), 0))
+    order = rng.permutation(len(src))
+    return [src[i] for i in order]
+
+
+def check_pk(order, src, batch, K, index_of=None):
+    """Every consecutive `batch` indices are batch // K identities x K samples, identities distinct within the batch."""
+    assert len(order) % batch == 0 and len(order) > 0
+    for b in range(0, len(order), batch):
+        pids = [src[i][1] for i in order[b:b + batch]]
+        groups = [pids[g:g + K] for g in range(0, batch, K)]
+        assert all(len(set(g)) == 1 for g in groups)
+        assert len({g[0] for g in groups}) == batch // K
+
+
+def test_pk_sampler_properties():
+    src = source()
+    K, batch = 4, 16
+    s = RandomIdentitySampler(src, batch, K, seed=3)
+    per_id = Counter(pid for _, pid, _, _ in src)
+    assert len(s) == sum(max(n, K) - max(n, K) % K for n in per_id.values())           # sampler.py:30-37
+    order = list(s)
+    assert len(order) <= len(s)
+    check_pk(order, src, batch, K)
+    used = Counter(src[i][1] for i in order)
+    for pid, n in per_id.items():
+        assert used[pid] % K == 0 and used[pid] <= max(n, K) - max(n, K) % K           # at most floor(n/K) groups per epoch
+    # identities with >= K samples are drawn without replacement inside the epoch; smaller ones are padded by replacement
+    seen = Counter(order)
+    for i, c in seen.items():
+        if per_id[src[i][1]] >= K:
+            assert c == 1
+    assert list(RandomIdentitySampler(src, batch, K, seed=3)) == order                 # seedable
+    assert list(s) != order                                                            # a new epoch is a new draw
+    with pytest.raises(ValueError):
+        RandomIdentitySampler(src, 18, 4)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference not mounted")
+def test_pk_sampler_against_reference_sampler():
+    """Same __len__, same batch structure and the same per-identity group budget as data/datasets/sampler.py."""
+    spec = importlib.util.spec_from_file_location("ref_sampler", os.path.join(REF, "data", "datasets", "sampler.py"))
+    sys.dont_write_bytecode = True
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    src = source(n_ids=50, seed=5)
+    K, batch = 4, 32
+    ref, mine = mod.RandomIdentitySampler(src, batch, K), RandomIdentitySampler(src, batch, K, seed=1)
+    assert len(ref) == len(mine)
+    r, m = list(ref), list(mine)
+    r = r[:len(r) - len(r) % batch]
+    check_pk(r, src, batch, K)
+    check_pk(m, src, batch, K)
+    # epoch sizes agree up to the random tail (the epoch stops when fewer than P identities still have a group)
+    assert abs(len(r) - len(m)) <= 4 * batch
+    per_id = Counter(pid for _, pid, _, _ in src)
+    for order in (r, m):
+        used = Counter(src[i][1] for i in order)
+        assert all(used[p] <= max(n, K) - max(n, K) % K for p, n in per_id.items())
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        src = source(n_ids=41, seed=2)
+        s = RandomIdentitySampler_DDP(src, 32, 4)                      # global batch 32 -> 16 per rank
+        np.random.seed(1000 + rank)                                    # ranks start from different global RNG states
+        first = list(s)
+        second = list(s)
+        q.put((rank, first, second, len(s), s.mini_batch_size))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_sampler_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    src = source(n_ids=41, seed=2)
+    (_, a1, a2, la, mb), (_, b1, b2, lb, _) = res
+    assert mb == 16 and la == lb == len(a2) == len(b2)
+    for a, b in ((a1, b1), (a2, b2)):
+        assert len(a) == len(b) and len(a) % 16 == 0 and len(a) > 0    # same number of mini-batches on every rank
+        check_pk(a, src, 16, 4)                                        # whole identities on each rank (triplet mining is local)
+        check_pk(b, src, 16, 4)
+        # the two ranks hold the two halves of one global P x K list drawn from the shared seed: reassemble and re-derive it
+        s0 = RandomIdentitySampler_DDP(src, 32, 4, rank=0, world_size=2)
+        glob = np.stack([np.asarray(a).reshape(-1, 16), np.asarray(b).reshape(-1, 16)], 1).reshape(-1)
+        per_id = Counter(pid for _, pid, _, _ in src)
+        used = Counter(src[i][1] for i in glob)
+        assert all(used[p] <= max(n, 4) - max(n, 4) % 4 for p, n in per_id.items())
+        assert s0.local_part(glob).tolist() == a
+    assert a1 != a2                                                    # epochs differ
+
+
+def test_ddp_sampler_partition_is_exact():
+    src = source(n_ids=30, seed=9, lo=4, hi=9)
+    parts = []
+    for r in range(4):
+        s = RandomIdentitySampler_DDP(src, 64, 4, rank=r, world_size=4, seed=7)
+        order = s.global_order(7)
+        parts.append(s.local_part(order))
+    n = len(parts[0])
+    assert all(len(p) == n for p in parts) and n % 16 == 0
+    inter = np.stack([p.reshape(-1, 16) for p in parts], 1).reshape(-1)
+    assert inter.tolist() == order[:len(inter)].tolist()               # block b of rank r = global block b*world + r
+    assert len(order) - len(inter) < 64                                # only an incomplete last round is dropped
+    with pytest.raises(ValueError):
+        RandomIdentitySampler_DDP(src, 24, 4, rank=0, world_size=4)
+
+
+def _items(B, h=8, w=4):
+    g = torch.Generator().manual_seed(0)
+    return [((torch.randn(3, h, w, generator=g), torch.randn(3, h, w, generator=g), torch.randn(3, h, w, generator=g)),
+             100 + b, b % 3, 0, f"path_{b}.jpg") for b in range(B)]
+
+
+def test_collate_layout():
+    items = _items(5)
+    imgs, pids, camids, viewids, paths = train_collate_fn(items)
+    assert set(imgs) == {"RGB", "NI", "TI"} and all(v.shape == (5, 3, 8, 4) and v.dtype == torch.float32 for v in imgs.values())
+    for m, k in enumerate(("RGB", "NI", "TI")):
+        for b in range(5):
+            assert torch.equal(imgs[k][b], items[b][0][m])
+    assert pids.dtype == camids.dtype == viewids.dtype == torch.int64 and pids.tolist() == [100, 101, 102, 103, 104]
+    assert camids.tolist() == [0, 1, 2, 0, 1] and paths == tuple(f"path_{b}.jpg" for b in range(5))
+    # one modality-major buffer underneath: the order in which the shared trunk batches the three modalities
+    step = imgs["RGB"].numel() * 4
+    assert imgs["NI"].data_ptr() == imgs["RGB"].data_ptr() + step and imgs["TI"].data_ptr() == imgs["RGB"].data_ptr() + 2 * step
+    v = val_collate_fn(items)
+    assert len(v) == 6 and isinstance(v[1], tuple) and v[1] == (100, 101, 102, 103, 104)        # pids stay a tuple (:167)
+    assert torch.equal(v[2], v[3]) and v[2].dtype == torch.int64 and torch.equal(v[0]["TI"], imgs["TI"])
+
+
+def test_device_feeder_cpu_device():
+    batches = [train_collate_fn(_items(4)), train_collate_fn(_items(3)), val_collate_fn(_items(2))]
+    out = list(DeviceFeeder(batches, "cpu"))
+    assert len(out) == 3
+    for got, want in zip(out, batches):
+        assert len(got) == len(want)
+        for k in ("RGB", "NI", "TI"):
+            assert torch.equal(got[0][k], want[0][k])
+        for g, w in zip(got[1:], want[1:]):
+            assert torch.equal(g, w) if torch.is_tensor(w) else g == w
+    assert list(DeviceFeeder([], "cpu")) == []

@@ -1,0 +1,41 @@
+"""GPU: the device feeder (demo2_amd/data/collate.py) hands batches to the model exactly as the per-modality .to(device) calls
+of engine/processor.py:60-64 would -- one pinned modality-major buffer, one asynchronous copy per batch on a side stream."""
+import pytest
+import torch
+
+from demo2_amd.data import DeviceFeeder, train_collate_fn
+from demo2_amd.modeling import make_model
+from oracle import demo_oracle as O
+from util import small_cfg, spec_of
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_feeder_batches_equal_direct_copies_and_feed_the_model():
+    cfg = small_cfg("clip")
+    torch.manual_seed(0)
+    m = make_model(cfg, 11, 3, 0)
+    m.load_state_dict(O.init_state_dict(spec_of(m), seed=1))
+    m = m.to(DEV).eval().set_compute_dtype(torch.float32)
+    g = torch.Generator().manual_seed(5)
+    batches = []
+    for _ in range(4):
+        items = [((torch.randn(3, 64, 32, generator=g), torch.randn(3, 64, 32, generator=g), torch.randn(3, 64, 32, generator=g)),
+                  int(torch.randint(0, 11, (1,), generator=g)), int(torch.randint(0, 3, (1,), generator=g)), 0, "p.jpg") for _ in range(6)]
+        batches.append(train_collate_fn(items))
+    outs = []
+    for imgs, pids, camids, viewids, paths in DeviceFeeder(batches, DEV):
+        assert all(v.is_cuda for v in imgs.values()) and pids.is_cuda and camids.is_cuda and isinstance(paths, tuple)
+        step = imgs["RGB"].numel() * 4
+        assert imgs["NI"].data_ptr() == imgs["RGB"].data_ptr() + step          # still one modality-major buffer on the device
+        with torch.no_grad():
+            outs.append((m(imgs, cam_label=camids).cpu(), {k: v.cpu() for k, v in imgs.items()}, pids.cpu()))
+    assert len(outs) == 4
+    for (feat, dev_imgs, pids), (imgs, hp, hc, _, _) in zip(outs, batches):
+        for k in imgs:
+            assert torch.equal(dev_imgs[k], imgs[k])
+        assert torch.equal(pids, hp)
+        with torch.no_grad():
+            want = m({k: v.to(DEV) for k, v in imgs.items()}, cam_label=hc.to(DEV)).cpu()
+        assert torch.equal(feat, want)
