@@ -118,7 +118,7 @@ def gemm_roofline(model, step_fn):
         torch.cuda.synchronize()
     finally:
         lib.demo_gemm = orig
-    names = {1: "gemm_bf16_nt_kernel<128,128,...>", 2: "gemm_bf16_nt_pp_kernel"}
+    names = {1: "gemm_bf16_nt_kernel<128,128,...>", 2: "gemm_bf16_nt_pp_kernel<true>"}
     stats = {}
     for path, rs in recs.items():
         if rs:

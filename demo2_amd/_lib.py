@@ -48,6 +48,7 @@ PROTOTYPES = {
     "demo_gemm_path": [C.POINTER(GemmDesc)],
     "demo_gemm_split_rows": [C.POINTER(GemmDesc)],
     "demo_gemm_set_split": [C.c_int],
+    "demo_gemm_set_pp_epilogue": [C.c_int],
     "demo_cast_f32_bf16": [_P, _P, _L, _P],
     "demo_cast_bf16_f32": [_P, _P, _L, _P],
     "demo_transpose": [_P, _P, _I, _I, _I, _P],

@@ -43,7 +43,14 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 // stage ROWS x 64 bf16 (ROWS*128 B) with NW waves: 1 KiB (8 rows) per wave instruction
-template <int ROWS, int NW>
+// PERM (weight operand of the 256^2 kernel's register epilogue): LDS row l of every 64-row panel receives global row
+// perm(l) = (j>>1)*32 + (x>>2)*8 + (j&1)*4 + (x&3) with j = l>>4 (the MFMA column tile) and x = l&15 (the row inside its fragment),
+// so that the lane holding output columns {4*(lane>>4) + r} of the four column tiles owns 2 x 8 CONSECUTIVE columns of C.
+__device__ __forceinline__ int perm64(int l) {
+  const int j = l >> 4, x = l & 15;
+  return ((j >> 1) << 5) | ((x >> 2) << 3) | ((j & 1) << 2) | (x & 3);
+}
+template <int ROWS, int NW, bool PERM = false>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int64_t ld, int row0, int row_max, int k0,
                                            char* lds_tile, int wave, int lane) {
   constexpr int NSEG = ROWS / 8;
@@ -52,7 +59,7 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int64_t
     const int seg = j * NW + wave;
     const int r = seg * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
-    int gr = row0 + r;
+    int gr = row0 + (PERM ? (r & ~63) + perm64(r & 63) : r);
     gr = gr < row_max ? gr : row_max - 1;     // clamp: rows past the edge are loaded but never stored
     const bf16_t* src = G + (int64_t)gr * ld + k0 + c * 8;
     __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(lds_tile + seg * 1024), 16, 0, 0);
@@ -280,6 +287,116 @@ __device__ __forceinline__ void epi_rows(const FArgs& p, const float* __restrict
     epi_rows_k<NIT, RSTEP, BN_, G, DEMO_ACT_NONE, DEMO_ACT_GELU>(p, ct, r0, mrow0, n, c, bz0, bz1, coff, epre, have_epre);
   else
     epi_rows_k<NIT, RSTEP, BN_, G, -1, -1>(p, ct, r0, mrow0, n, c, bz0, bz1, coff, epre, have_epre);
+}
+
+// ---- register epilogue of the 256^2 kernel --------------------------------------------------------------------------------------
+// With the weight rows staged in perm64 order a lane (frow = lane & 15, g4 = lane >> 4) of wave (wr, wc) holds, for each of its 8
+// row tiles i, C[m0 + wr*128 + i*16 + frow][n0 + wc*64 + h*32 + g4*8 + 0..7] for h = 0, 1 in acc[i][2h], acc[i][2h+1]: two 8-column
+// chunks, each one 16-B bf16 store (or 2 x 16 B of fp32).  No LDS image of the tile and no barrier: the eight waves finish their rows
+// independently (the LDS-staged form wrote and re-read 256 KB of LDS per tile behind four workgroup barriers), and four lanes of
+// a store instruction cover 64 contiguous bytes of a row.  Rows are finished G row tiles at a time, every global operand of the
+// group requested first.
+// LOADS: which global operands besides the bias the epilogue reads, as a compile-time mask (1 residual, 2 act'(pre) source in bf16,
+// 0 none) or -1 = decided at run time (any combination, G = 1: every unit then budgets all 24 operand registers).
+template <int G, int ACT, int GK, int LOADS>
+__device__ __forceinline__ void pp_epi_k(const FArgs& p, const f32x4 (&acc)[8][4], int mrow, int ncol, int64_t coff, const float* bias) {
+  const bool has_pre = LOADS >= 0 ? (LOADS & 2) != 0 : (GK >= 0 ? GK != DEMO_ACT_NONE : p.pre != nullptr);
+  const bool has_res = LOADS >= 0 ? (LOADS & 1) != 0 : p.residual != nullptr;
+  const bool has_old = LOADS >= 0 ? false : (p.accumulate && p.dtC == DEMO_F32);
+  const bool pre_bf16 = LOADS >= 0 ? true : p.dtPre == DEMO_BF16;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 bz[2][2] = {{z4, z4}, {z4, z4}};
+  if (bias) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      bz[h][0] = *reinterpret_cast<const float4*>(bias + ncol + h * 32);
+      bz[h][1] = *reinterpret_cast<const float4*>(bias + ncol + h * 32 + 4);
+    }
+  }
+#pragma unroll
+  for (int i0 = 0; i0 < 8; i0 += G) {
+    EpiOps x[G][2];
+    int64_t ci[G][2];
+    bool ok[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int m = mrow + (i0 + u) * 16;
+      ok[u] = m < p.M;
+      const int64_t rb = coff + (int64_t)(ok[u] ? m : p.M - 1) * p.ldc + ncol;     // clamped for the loads; stores are guarded
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        ci[u][h] = rb + h * 32;
+        x[u][h].pre0 = x[u][h].pre1 = x[u][h].res0 = x[u][h].res1 = x[u][h].old0 = x[u][h].old1 = z4;
+      }
+    }
+    if (has_pre) {
+      if (pre_bf16) {
+        uint4 raw[G][2];
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) raw[u][h] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.pre) + ci[u][h]);
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) bf16x8_to_f32(raw[u][h], x[u][h].pre0, x[u][h].pre1);
+      } else {
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            x[u][h].pre0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.pre) + ci[u][h]);
+            x[u][h].pre1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.pre) + ci[u][h] + 4);
+          }
+      }
+    }
+    if (has_res) {
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          x[u][h].res0 = *reinterpret_cast<const float4*>(p.residual + ci[u][h]);
+          x[u][h].res1 = *reinterpret_cast<const float4*>(p.residual + ci[u][h] + 4);
+        }
+    }
+    if (has_old) {
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          x[u][h].old0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.C) + ci[u][h]);
+          x[u][h].old1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.C) + ci[u][h] + 4);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      if (!ok[u]) continue;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 a = acc[i0 + u][2 * h], b = acc[i0 + u][2 * h + 1];
+        float v[8] = {a[0] * p.alpha, a[1] * p.alpha, a[2] * p.alpha, a[3] * p.alpha, b[0] * p.alpha, b[1] * p.alpha, b[2] * p.alpha, b[3] * p.alpha};
+        epi8_finish<ACT, GK>(p, bz[h][0], bz[h][1], x[u][h], ci[u][h], v);
+      }
+    }
+  }
+}
+__device__ __forceinline__ void pp_epi(const FArgs& p, const f32x4 (&acc)[8][4], int mrow, int ncol, int64_t coff, const float* bias) {
+  const int gk = p.pre ? p.act_grad_kind : DEMO_ACT_NONE;
+  const bool old = p.accumulate && p.dtC == DEMO_F32;
+  if (!p.pre && !p.residual && !old) {                       // nothing to read but the bias: trunk qkv / fc1 forward, plain dX products
+    if (p.act == DEMO_ACT_NONE) pp_epi_k<1, DEMO_ACT_NONE, DEMO_ACT_NONE, 0>(p, acc, mrow, ncol, coff, bias);
+    else if (p.act == DEMO_ACT_QUICKGELU) pp_epi_k<1, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE, 0>(p, acc, mrow, ncol, coff, bias);
+    else if (p.act == DEMO_ACT_GELU) pp_epi_k<1, DEMO_ACT_GELU, DEMO_ACT_NONE, 0>(p, acc, mrow, ncol, coff, bias);
+    else pp_epi_k<1, -1, -1, -1>(p, acc, mrow, ncol, coff, bias);
+  } else if (p.residual && !p.pre && !old && p.act == DEMO_ACT_NONE) {       // proj / fc2 forward: + fp32 residual
+    pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_NONE, 1>(p, acc, mrow, ncol, coff, bias);
+  } else if (p.pre && p.dtPre == DEMO_BF16 && !p.residual && !old && p.act == DEMO_ACT_NONE && gk == DEMO_ACT_QUICKGELU) {
+    pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_QUICKGELU, 2>(p, acc, mrow, ncol, coff, bias);   // MLP backward: (dY W2^T) * act'(pre)
+  } else if (p.pre && p.dtPre == DEMO_BF16 && !p.residual && !old && p.act == DEMO_ACT_NONE && gk == DEMO_ACT_GELU) {
+    pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_GELU, 2>(p, acc, mrow, ncol, coff, bias);
+  } else {
+    pp_epi_k<1, -1, -1, -1>(p, acc, mrow, ncol, coff, bias);
+  }
 }
 
 __device__ __forceinline__ unsigned lds_off(const char* p) {
@@ -532,6 +649,7 @@ __device__ __forceinline__ void lds_read2(bf16x8 (&f)[2], unsigned base) {
 //   P4: (b0 still in registers)  vmcnt(0) before the first barrier                      MFMA acc[4..7][0..1]
 // Hazards: tile t+1 is read (P1 of t+1) two barriers after every wave's own vmcnt(0); buffer (t+1)&1 is re-staged at P1/P2 of
 // tile t, four barriers after its last ds_read (P3 of tile t-1) was waited for by the later half.
+template <bool REG_EPI>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) {
   constexpr int BM = 256, BN = 256, NW = 8;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -579,7 +697,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
   // was tried -- 2/4/8 phase groups, 7..17 us apart -- and measured 2..6 % slower on the training step.)
   // first K-tiles: A(0) -> A slot 0, B(0) -> B slot 1, A(1) -> A slot 1
   stage_tile<BM, NW>(A, p.lda, m0, p.M, 0, smem, wave, lane);
-  stage_tile<BN, NW>(B, p.ldb, n0, p.N, 0, smem_b + B_BYTES, wave, lane);
+  stage_tile<BN, NW, REG_EPI>(B, p.ldb, n0, p.N, 0, smem_b + B_BYTES, wave, lane);
   if (nk > 1) {
     stage_tile<BM, NW>(A, p.lda, m0, p.M, BK, smem + A_BYTES, wave, lane);
     wait_vmcnt<4>();                                // K-tile 0 landed; A(1), the 4 youngest loads, may still fly
@@ -616,7 +734,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
     lds_read2(b0f[1], lb + foff1);
     lds_read4(af[0], la + foff0);
     lds_read4(af[1], la + foff1);
-    if (has1) stage_tile<BN, NW>(B, p.ldb, n0, p.N, (t + 1) * BK, smem_b + (t & 1) * B_BYTES, wave, lane);
+    if (has1) stage_tile<BN, NW, REG_EPI>(B, p.ldb, n0, p.N, (t + 1) * BK, smem_b + (t & 1) * B_BYTES, wave, lane);
     PP_MFMA(af, b0f, 0, 0);
     // ---- P2
     lds_read2(b1f[0], lb + 4096 + foff0);
@@ -642,8 +760,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
   // four-quarter form of this loop (3x the instructions) measured 25 % slower end to end on K = 768 -- instruction fetch.
   const int64_t coff = z * p.sC;
   const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
-  float* ct = reinterpret_cast<float*>(smem);
   const int g4 = lane >> 4;
+  if constexpr (REG_EPI) {
+    // register epilogue (see pp_epi_k): no LDS image, no barrier
+    pp_epi(p, acc, m0 + wr * 128 + frow, n0 + wc * 64 + g4 * 8, coff, bias);
+    return;
+  }
+  float* ct = reinterpret_cast<float*>(smem);
   const int c = threadIdx.x & 31;                   // this thread's 8-column chunk, the same in every pass
   float4 bz0 = make_float4(0.f, 0.f, 0.f, 0.f), bz1 = bz0;
   if (bias) {
@@ -703,6 +826,7 @@ int demo_gemm_bf16_eligible(const demo_gemm_desc& d) {
 }
 
 static int g_force_tile = 0;   // test/bench hook: 128 or 256 forces a configuration, 0 = heuristic
+static int g_pp_reg_epi = 1;   // 256^2 kernel: 1 = register epilogue over permuted weight rows, 0 = LDS-staged row-major epilogue
 void demo_gemm_tn_force(int t);
 // 1280: only pins the weight-gradient (TN) product to its 128^2 form, 1290: to the 256^2 form with fp32 atomics (no two-pass
 // split-K); 0 restores the heuristics of both
@@ -721,7 +845,9 @@ int demo_gemm_bf16_config(const demo_gemm_desc& d) {
     // ~1.4 PF/s marginal against ~1.1 for the 128^2 kernel, outweighs the last partial round); measured crossover on
     // M = 49536: N = 2304 / 3072 always, N = 768 from K = 2048
     cfg = 1282;
-    if (d.N % 256 == 0 && d.M >= 1024 && !d.act_grad_pre) {      // (act'(pre) epilogue: 128^2 378 us vs 256^2 411 us at N=3072, K=768)
+    // act'(pre) epilogue at N=3072, K=768: 128^2 344 us, 256^2 with the LDS-staged epilogue 382 us (its operand registers spill), 256^2
+    // with the register epilogue 319 us
+    if (d.N % 256 == 0 && d.M >= 1024 && (!d.act_grad_pre || (g_pp_reg_epi && d.dtPre == DEMO_BF16))) {
       const double rounds = (double)cdiv64(d.M, 256) * (d.N / 256) * nb / 256.0;
       const double eff = rounds / (double)(int64_t)(rounds + 0.999999);
       if (eff >= 0.85 || d.K >= 2048) cfg = 2566;
@@ -735,6 +861,7 @@ int demo_gemm_bf16_config(const demo_gemm_desc& d) {
 // M = 49536: a third round running 27 % full): the rows that fill whole rounds go to the 256^2 kernel, the rest to the 128^2
 // kernel, whose 4x smaller tiles at 2 workgroups/CU cover them in one short round.  Returns the rows of the first part
 // (a multiple of 256), 0 = no split.  g_split_left: largest leftover (in 256^2 tiles) that is split off; 0 disables.
+extern "C" int demo_gemm_set_pp_epilogue(int reg) { g_pp_reg_epi = reg != 0; return 0; }
 static int g_split_left = 128;
 extern "C" int demo_gemm_set_split(int max_left_tiles) { g_split_left = max_left_tiles; return 0; }
 int demo_gemm_bf16_split_rows(const demo_gemm_desc& d) {
@@ -742,7 +869,7 @@ int demo_gemm_bf16_split_rows(const demo_gemm_desc& d) {
   if (demo_gemm_bf16_config(d) != 2566) return 0;
   const int64_t ntm = cdiv64(d.M, 256), ntn = d.N / 256, total = ntm * ntn;
   const int64_t full = total / 256, left = total - full * 256;
-  if (full < 1 || left == 0 || left > g_split_left) return 0;
+  if (full < 1 || left < 32 || left > g_split_left) return 0;   // (a last round under ~1/8 full finishes fast enough on its own: fc1 forward, 24 tiles, measured)
   const int64_t tm1 = full * 256 / ntn;
   if (tm1 < 1 || tm1 * 256 >= d.M) return 0;
   return (int)(tm1 * 256);
@@ -809,7 +936,10 @@ int demo_gemm_bf16(const demo_gemm_desc& d, hipStream_t s) {
       p.ntm = (int)cdiv64(d.M, 256);
       p.ntn = d.N / 256;
       p.group_m = 32 / p.ntn < 1 ? 1 : (32 / p.ntn > 8 ? 8 : 32 / p.ntn);      // (2..8 measured within 1 % of each other)
-      hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel, dim3((unsigned)(p.ntm * p.ntn), (unsigned)nb), dim3(512), 0, s, p);
+      if (g_pp_reg_epi)
+        hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<true>, dim3((unsigned)(p.ntm * p.ntn), (unsigned)nb), dim3(512), 0, s, p);
+      else
+        hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<false>, dim3((unsigned)(p.ntm * p.ntn), (unsigned)nb), dim3(512), 0, s, p);
       break;
     case 1292: LAUNCH_RS(128, 128, 2, 2); break;
     case 2592: LAUNCH_RS(256, 128, 4, 2); break;

@@ -38,4 +38,4 @@ def test_feeder_batches_equal_direct_copies_and_feed_the_model():
         assert torch.equal(pids, hp)
         with torch.no_grad():
             want = m({k: v.to(DEV) for k, v in imgs.items()}, cam_label=hc.to(DEV)).cpu()
-        assert torch.equal(feat, want)
+        torch.testing.assert_close(feat, want, rtol=1e-4, atol=1e-5)      # (split-K atomics: summation order varies run to run)

@@ -91,6 +91,63 @@ def test_gemm_bf16_mfma(M, N, K):
         assert torch.equal(got.cpu(), a2.bfloat16().float() @ b2.bfloat16().float().t())
 
 
+@pytest.mark.parametrize("reg_epi", [1, 0])
+@pytest.mark.parametrize("M,N,K", [(700, 512, 192), (1300, 256, 64), (256, 768, 128)])
+def test_gemm_bf16_256_kernel_epilogues(M, N, K, reg_epi):
+    """The 256x256 ping-pong kernel forced (the heuristic only takes it on chip-filling shapes), both epilogue forms: the register
+    epilogue stages the weight rows in a permuted order, so an exact asymmetric-integer product checks the column map; then
+    every epilogue variant the path uses (bias, QuickGELU + saved pre-activation, fp32 residual, act'(pre), accumulate),
+    ragged M, and the row split."""
+    from demo2_amd import _lib
+    lib = _lib.load()
+    lib.demo_gemm_set_pp_epilogue(reg_epi)
+    lib.demo_gemm_force_tile(2566)
+    try:
+        a2 = torch.zeros(M, K)
+        a2[:K, :K] = torch.eye(K)
+        a2[K:, :] = (torch.arange(M - K)[:, None] % 3 - 1).float() * (torch.arange(K)[None, :] % 2)
+        b2 = (torch.arange(N)[:, None] * 2 + torch.arange(K)[None, :] % 7).float() % 251
+        got = ops.gemm(a2.bfloat16().to(DEV), b2.bfloat16().to(DEV), out_dtype=torch.float32)
+        assert torch.equal(got.cpu(), a2.bfloat16().float() @ b2.bfloat16().float().t())
+        a, b, bias, res = rnd(M, K).bfloat16(), rnd(N, K, seed=1, scale=K ** -0.5).bfloat16(), rnd(N, seed=2), rnd(M, N, seed=3)
+        ref = a.float() @ b.float().t()
+        ad, bd = a.to(DEV), b.to(DEV)
+        got, pre = ops.gemm(ad, bd, bias=bias.to(DEV), act=ACT_QUICKGELU, pre_out_new=True)                       # fc1 forward
+        assert got.dtype == torch.bfloat16
+        torch.testing.assert_close(got.float().cpu(), O.quick_gelu(ref + bias), rtol=1e-2, atol=1e-2)
+        torch.testing.assert_close(pre.float().cpu(), ref + bias, rtol=1e-2, atol=1e-2)
+        got = ops.gemm(ad, bd, bias=bias.to(DEV), residual=res.to(DEV), out_dtype=torch.float32, alpha=0.5)       # proj / fc2 forward
+        torch.testing.assert_close(got.cpu(), 0.5 * ref + bias + res, rtol=1e-3, atol=1e-3)
+        for kind in (ACT_QUICKGELU, ACT_GELU):                                                                  # MLP backward
+            pr = rnd(M, N, seed=5).bfloat16().float().requires_grad_(True)
+            act_ref(pr, kind).sum().backward()
+            got = ops.gemm(ad, bd, act_grad_pre=pr.detach().bfloat16().to(DEV), act_grad_kind=kind)
+            torch.testing.assert_close(got.float().cpu(), ref * pr.grad, rtol=2e-2, atol=2e-2)
+        acc = rnd(M, N, seed=9)
+        got = ops.gemm(ad, bd, out=acc.to(DEV), accumulate=True)
+        torch.testing.assert_close(got.cpu(), acc + ref, rtol=1e-3, atol=1e-3)
+    finally:
+        lib.demo_gemm_force_tile(0)
+        lib.demo_gemm_set_pp_epilogue(1)
+
+
+def test_gemm_bf16_row_split_matches_single_launch():
+    from demo2_amd import _lib
+    lib = _lib.load()
+    M, N, K = 162 * 256 - 7, 768, 64           # 486 tiles of 256^2 = 1.9 rounds: the heuristic takes the 256^2 kernel, 230 tiles left over
+    a, b, bias = rnd(M, K).bfloat16().to(DEV), rnd(N, K, seed=1, scale=K ** -0.5).bfloat16().to(DEV), rnd(N, seed=2).to(DEV)
+    outs = []
+    try:
+        for left in (0, 250):
+            lib.demo_gemm_set_split(left)
+            lib.demo_gemm_force_tile(0)
+            outs.append(ops.gemm(a, b, bias=bias, out_dtype=torch.float32).cpu())
+    finally:
+        lib.demo_gemm_set_split(128)
+    torch.testing.assert_close(outs[0], outs[1], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(outs[1], a.float().cpu() @ b.float().cpu().t() + bias.cpu(), rtol=1e-3, atol=1e-3)
+
+
 def test_gemm_bf16_batched_and_in_place_residual():
     Z, M, N, K = 3, 130, 128, 64
     A, B = rnd(Z, M, K).bfloat16(), rnd(Z, N, K, seed=1).bfloat16()

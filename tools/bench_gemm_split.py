@@ -38,8 +38,11 @@ def timeit(fn, reps):
 
 # name, N, K, epilogue
 cases = [("qkv fwd", 3 * W, W, "bias"), ("fc1 fwd", 4 * W, W, "bias+act+pre"), ("fc2 fwd", W, 4 * W, "bias+res"),
-         ("dqkv->dh1", W, 3 * W, "plain"), ("dfc1->dh2", W, 4 * W, "plain"), ("proj fwd", W, W, "bias+res")]
+         ("dqkv->dh1", W, 3 * W, "plain"), ("dfc1->dh2", W, 4 * W, "plain"), ("proj fwd", W, W, "bias+res"),
+         ("dfc2->dpre", 4 * W, W, "actgrad")]
 lefts = [int(v) for v in a.left.split(",")]
+# variants: (label, register epilogue?, split leftover, forced tile)
+variants = [("lds", 0, 0, 0), ("lds+split", 0, 128, 0), ("reg", 1, 0, 0), ("reg+split", 1, 128, 0)]
 for name, n, k, epi in cases:
     x = torch.randn(M, k, device=dev).bfloat16()
     w = (torch.randn(n, k, device=dev) * k ** -0.5).bfloat16()
@@ -47,30 +50,44 @@ for name, n, k, epi in cases:
     res = torch.randn(M, n, device=dev) if "res" in epi else None
     odt = torch.float32 if res is not None else torch.bfloat16
 
+    gpre = torch.randn(M, n, device=dev).bfloat16() if epi == "actgrad" else None
+
     def run(out, pre):
-        ops.gemm(x, w, out=out, bias=bias if "bias" in epi else None, residual=res, act=ACT_QUICKGELU if "act" in epi else 0,
-                 pre_out=pre)
+        ops.gemm(x, w, out=out, bias=bias if "bias" in epi else None, residual=res, act=ACT_QUICKGELU if "act+" in epi else 0,
+                 pre_out=pre, act_grad_pre=gpre, act_grad_kind=ACT_QUICKGELU if gpre is not None else 0)
+
+    vs = list(variants)
+    if epi == "actgrad":                                  # the dispatcher's default for this epilogue is the 128^2 kernel
+        vs = [("128^2 (default)", 1, 0, 0), ("256^2 lds", 0, 0, 2566), ("256^2 reg", 1, 0, 2566)]
+
+    def setup(v):
+        lib.demo_gemm_set_pp_epilogue(v[1])
+        lib.demo_gemm_set_split(v[2])
+        lib.demo_gemm_force_tile(v[3])
 
     outs = []
-    for left in [0] + lefts:
-        lib.demo_gemm_set_split(left)
+    for v in vs:
+        setup(v)
         out = torch.empty(M, n, device=dev, dtype=odt)
         pre = torch.empty(M, n, device=dev, dtype=odt) if "pre" in epi else None
         run(out, pre)
         outs.append((out.float(), None if pre is None else pre.float()))
-    for o, p_ in outs[1:]:
-        assert (o - outs[0][0]).abs().max().item() <= 2e-2 * outs[0][0].abs().max().item(), name
+    for (o, p_), v in zip(outs[1:], vs[1:]):
+        err = (o - outs[0][0]).abs().max().item() / outs[0][0].abs().max().item()
+        assert err <= 2e-2, (name, v[0], err)
         if p_ is not None:
-            assert (p_ - outs[0][1]).abs().max().item() <= 2e-2 * outs[0][1].abs().max().item(), name
+            assert (p_ - outs[0][1]).abs().max().item() <= 2e-2 * outs[0][1].abs().max().item(), (name, v[0])
     out = torch.empty(M, n, device=dev, dtype=odt)
     pre = torch.empty(M, n, device=dev, dtype=odt) if "pre" in epi else None
     t = {}
     for rnd in range(3):
-        for left in [0] + lefts:
-            lib.demo_gemm_set_split(left)
-            t.setdefault(left, []).append(timeit(lambda: run(out, pre), a.reps))
+        for v in vs:
+            setup(v)
+            t.setdefault(v[0], []).append(timeit(lambda: run(out, pre), a.reps))
     fl = 2.0 * M * n * k
     tiles = -(-M // 256) * (n // 256)
     print(f"{name:10s} N={n:5d} K={k:5d} {epi:13s} tiles {tiles:5d} ({tiles / 256:5.2f} rounds): " +
-          "  ".join(f"left<={lf}: {min(v) * 1e3:6.1f} us {fl / min(v) / 1e9:5.0f} TF" for lf, v in t.items()), flush=True)
+          "  ".join(f"{lf}: {min(v) * 1e3:6.1f} us {fl / min(v) / 1e9:5.0f} TF" for lf, v in t.items()), flush=True)
+lib.demo_gemm_force_tile(0)
+lib.demo_gemm_set_pp_epilogue(1)
 lib.demo_gemm_set_split(128)
