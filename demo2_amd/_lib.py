@@ -123,6 +123,11 @@ def load():
     lib.demo_last_error.restype = C.c_char_p
     if lib.demo_gemm_desc_size() != C.sizeof(GemmDesc):
         raise DemoHipError("demo_gemm_desc layout mismatch between include/demo_hip.h and demo2_amd/_lib.py")
+    # tuning hooks for same-box A/B runs of whole steps (defaults are the measured-best settings)
+    if "DEMO_PP_EPILOGUE" in os.environ:
+        lib.demo_gemm_set_pp_epilogue(int(os.environ["DEMO_PP_EPILOGUE"]))      # 0: LDS-staged epilogue of the 256^2 NT kernel
+    if "DEMO_GEMM_SPLIT" in os.environ:
+        lib.demo_gemm_set_split(int(os.environ["DEMO_GEMM_SPLIT"]))             # 0: no row split of partial-round products
     _lib = lib
     return lib
 
