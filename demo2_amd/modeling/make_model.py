@@ -361,8 +361,14 @@ class DeMo(_Holder):
         lp = self.compute_dtype == torch.bfloat16
         if lp and P.shadow is None:
             P.shadow = torch.empty(P.flat.numel(), device=P.flat.device, dtype=torch.bfloat16)
+        # parameters the reference's optimizer never sees (requires_grad False: the BNNeck biases, make_model.py:137,177; make_optimizer.py:6-8)
+        # have no gradient, but the flat step would still apply weight decay to them: keep their values
+        frozen = [(p_, p_.detach().clone()) for p_ in self.parameters() if not p_.requires_grad] if weight_decay != 0 else []
         ops.adam_step(P.flat, self.grad_buffer(), m, v, P.shadow if lp else None, lr, beta1, beta2, eps, weight_decay, t, zero_grad=True,
                       hyper_dev=hyper_dev)
+        with torch.no_grad():
+            for p_, keep in frozen:
+                p_.copy_(keep)
         self._refresh_derived()
         P.shadow_version = (self._param_version(), bool(self.training), self.compute_dtype)
 

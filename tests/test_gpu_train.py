@@ -99,7 +99,11 @@ def test_small_train_step_bf16_and_adam():
         p.grad = got[n].clone()
     opt = torch.optim.Adam([{"params": [p], "lr": 1e-3, "weight_decay": 1e-4} for p in params.values()])
     opt.step()
+    with torch.no_grad():
+        m.bottleneck.bias.fill_(0.37)                                        # frozen (make_model.py:177): no optimizer may move it
+    moe_bias = m.bottleneck_moe.bias.detach().clone()
     m.adam_step(ts.m, ts.v, 1e-3, 0.9, 0.999, 1e-8, 1e-4, 1)
+    assert torch.all(m.bottleneck.bias == 0.37) and torch.equal(m.bottleneck_moe.bias.detach(), moe_bias)
     for n, p in m.named_parameters():
         if p.requires_grad:
             torch.testing.assert_close(p.detach().cpu(), params[n].detach(), rtol=1e-5, atol=1e-6)
