@@ -141,3 +141,32 @@ def test_synthetic_map_parity_bf16():
     cmc_r, map_r = O.r1_map(torch.cat(feats_ref), pid, camid, nq, max_rank=10)
     cmc_h, map_h = O.r1_map(torch.cat(feats_hip), pid, camid, nq, max_rank=10)
     assert abs(map_r - map_h) * 100 <= 0.1 and abs(cmc_r[0] - cmc_h[0]) * 100 <= 0.1, (map_r, map_h, cmc_r[0], cmc_h[0])
+
+
+def test_bench_size_properties_bf16():
+    """BASELINE.json's sizes (config A, bf16, B = 64 eval / 128 train) are too big for the CPU oracle to finish in seconds, so
+    they are checked through size-independent properties of the path:
+      * samples are independent in eval (LayerNorm + running-stat BatchNorm): the features of a batch of 64 equal those of its
+        two halves run separately (different tile/row-split decisions of the GEMM dispatcher: bf16 noise only);
+      * a missing modality at eval (TEST.MISS) is exactly the same as feeding zero images for it (make_model.py:233-239);
+      * the batch order does not matter: permuting the samples permutes the features."""
+    cfg = make_cfg("RGBNT201")
+    m, _ = build(cfg, 171, 4, dtype=torch.bfloat16)
+    x, cam = synth_batch(64, 256, 128, 4, seed=11)
+    xd, camd = {k: v.to(DEV) for k, v in x.items()}, cam.to(DEV)
+    with torch.no_grad():
+        full = m(xd, cam_label=camd).cpu()
+        halves = torch.cat([m({k: v[:32] for k, v in xd.items()}, cam_label=camd[:32]).cpu(),
+                            m({k: v[32:] for k, v in xd.items()}, cam_label=camd[32:]).cpu()])
+        perm = torch.randperm(64, generator=torch.Generator().manual_seed(3))
+        shuffled = m({k: v[perm.to(DEV)] for k, v in xd.items()}, cam_label=camd[perm.to(DEV)]).cpu()
+    assert full.shape == (64, 5120) and torch.isfinite(full).all()
+    assert (full - halves).abs().max() < 2e-2 and (full - halves).norm() / full.norm() < 2e-3
+    assert (full[perm] - shuffled).abs().max() < 2e-2
+    m.miss_type = "n"
+    with torch.no_grad():
+        miss = m(xd, cam_label=camd).cpu()
+    m.miss_type = "nothing"
+    with torch.no_grad():
+        zeroed = m(dict(xd, NI=torch.zeros_like(xd["NI"])), cam_label=camd).cpu()
+    assert (miss - zeroed).abs().max() < 2e-2 and (miss - full).abs().max() > 0.1

@@ -160,3 +160,25 @@ def test_graph_replay_matches_eager_steps():
     diff = (flats[1] - flats[0]).abs()
     assert diff.max().item() < 5 * 1e-3
     assert (diff > 1e-5).float().mean().item() < 1e-3
+
+
+def test_bench_size_gradient_accumulation_is_linear_bf16():
+    """B = 128, config A, bf16 (the bench workload): gradients ACCUMULATE into the flat buffer, so two backward passes over the
+    same batch must give twice the gradient of one (dropout off; everything else in the step is deterministic up to the
+    summation order of atomics), and the loss must not depend on how often it was evaluated."""
+    cfg = make_cfg("RGBNT201")
+    m, _ = build(cfg, 171, 4, torch.bfloat16)
+    x, cam = synth_batch(128, 256, 128, 4, seed=21)
+    xd, camd = {k: v.to(DEV) for k, v in x.items()}, cam.to(DEV)
+    target = (torch.arange(128, device=DEV) // 4) % 171
+    ts = TrainStep(m, cfg, 1, optimizer=False)
+    m._nbt_flat.zero_()
+    l1 = ts.step(xd, target, camd).item()
+    g1 = m.grad_buffer().clone()
+    l2 = ts.step(xd, target, camd).item()
+    g2 = m.grad_buffer().clone()
+    torch.cuda.synchronize()
+    assert abs(l1 - l2) < 1e-3 * abs(l1) and torch.isfinite(g1).all()
+    rel = ((g2 - 2 * g1).norm() / (2 * g1).norm()).item()
+    assert rel < 2e-3, rel
+    assert int(m._nbt_flat[0]) == 2                                  # every BatchNorm saw two batches
