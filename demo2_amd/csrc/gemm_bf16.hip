@@ -662,8 +662,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
 
-  // XCD-aware tile id (as in the 128^2 kernel).  A persistent variant that requested the next output tile's first K-tiles
-  // before the epilogue measured no faster and costs registers; one output tile per workgroup it is.
+  // XCD-aware tile id (as in the 128^2 kernel).  One output tile per workgroup: a persistent variant (256 workgroups walking
+  // their XCD's tile list, the next tile's first K-tiles requested before the epilogue) was measured twice -- with the LDS-staged
+  // epilogue (no faster, +30 VGPRs) and with the register epilogue, where the LDS is free during the epilogue (qkv forward 179 ->
+  // 211 us, fc1 forward 295 -> 334: the loop-carried addresses spill, the static tile assignment loses the dispatcher's dynamic
+  // balancing, and the wait for the next tile's loads also waits for the epilogue's stores).
   const int nwg = p.ntm * p.ntn;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
