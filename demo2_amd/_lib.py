@@ -49,6 +49,7 @@ PROTOTYPES = {
     "demo_gemm_split_rows": [C.POINTER(GemmDesc)],
     "demo_gemm_set_split": [C.c_int],
     "demo_gemm_set_pp_epilogue": [C.c_int],
+    "demo_gemm_set_pp_min_fill": [C.c_int],
     "demo_cast_f32_bf16": [_P, _P, _L, _P],
     "demo_cast_bf16_f32": [_P, _P, _L, _P],
     "demo_transpose": [_P, _P, _I, _I, _I, _P],
@@ -126,6 +127,8 @@ def load():
     # tuning hooks for same-box A/B runs of whole steps (defaults are the measured-best settings)
     if "DEMO_PP_EPILOGUE" in os.environ:
         lib.demo_gemm_set_pp_epilogue(int(os.environ["DEMO_PP_EPILOGUE"]))      # 0: LDS-staged epilogue of the 256^2 NT kernel
+    if "DEMO_PP_MIN_FILL" in os.environ:
+        lib.demo_gemm_set_pp_min_fill(int(os.environ["DEMO_PP_MIN_FILL"]))      # 85: the pre-register-epilogue kernel choice
     if "DEMO_GEMM_SPLIT" in os.environ:
         lib.demo_gemm_set_split(int(os.environ["DEMO_GEMM_SPLIT"]))             # 0: no row split of partial-round products
     _lib = lib

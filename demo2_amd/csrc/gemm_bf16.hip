@@ -830,6 +830,8 @@ int demo_gemm_bf16_eligible(const demo_gemm_desc& d) {
 
 static int g_force_tile = 0;   // test/bench hook: 128 or 256 forces a configuration, 0 = heuristic
 static int g_pp_reg_epi = 1;   // 256^2 kernel: 1 = register epilogue over permuted weight rows, 0 = LDS-staged row-major epilogue
+static int g_pp_min_eff_pct = 70;
+extern "C" int demo_gemm_set_pp_min_fill(int pct) { g_pp_min_eff_pct = pct; return 0; }
 void demo_gemm_tn_force(int t);
 // 1280: only pins the weight-gradient (TN) product to its 128^2 form, 1290: to the 256^2 form with fp32 atomics (no two-pass
 // split-K); 0 restores the heuristics of both
@@ -853,7 +855,11 @@ int demo_gemm_bf16_config(const demo_gemm_desc& d) {
     if (d.N % 256 == 0 && d.M >= 1024 && (!d.act_grad_pre || (g_pp_reg_epi && d.dtPre == DEMO_BF16))) {
       const double rounds = (double)cdiv64(d.M, 256) * (d.N / 256) * nb / 256.0;
       const double eff = rounds / (double)(int64_t)(rounds + 0.999999);
-      if (eff >= 0.85 || d.K >= 2048) cfg = 2566;
+      // fill threshold of the last round: 0.85 was the measured crossover with the LDS-staged epilogue; with the register epilogue
+      // (and the row split taking care of small leftovers) the 256^2 kernel also wins at 2.27 and 1.52 rounds with K = 768
+      // (dY.W_proj 74.8 -> 71.6 us, CLIP projection 57.2 -> 50.7)
+      const double min_eff = g_pp_reg_epi ? g_pp_min_eff_pct * 0.01 : 0.85;
+      if (eff >= min_eff || d.K >= 2048) cfg = 2566;
     }
   }
   if ((cfg == 2562 || cfg == 2566) && d.N % 256) cfg = 1282;

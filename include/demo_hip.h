@@ -71,6 +71,7 @@ int demo_gemm_force_tile(int tile); /* tuning hook: 128 / 256 forces that MFMA t
  * (whole rounds of the 256 CUs) and rows [r, M) on the 128x128 kernel.  demo_gemm_split_rows: the r demo_gemm would use
  * (0 = one launch); demo_gemm_set_split: largest leftover, in 256x256 tiles, that is split off (default 128, 0 = never). */
 int demo_gemm_split_rows(const demo_gemm_desc* d);
+int demo_gemm_set_pp_min_fill(int pct); /* tuning hook: least fill (%) of the last round of 256 CUs at which short-K products still take the 256x256 kernel (default 70) */
 int demo_gemm_set_pp_epilogue(int reg); /* tuning hook, 256x256 kernel: 1 (default) = epilogue straight from the accumulators, 0 = LDS-staged */
 int demo_gemm_set_split(int max_left_tiles);
 int demo_gemm_desc_size(void); /* sizeof(demo_gemm_desc): lets a foreign binding verify its struct layout */

@@ -39,7 +39,7 @@ def timeit(fn, reps):
 # name, N, K, epilogue
 cases = [("qkv fwd", 3 * W, W, "bias"), ("fc1 fwd", 4 * W, W, "bias+act+pre"), ("fc2 fwd", W, 4 * W, "bias+res"),
          ("dqkv->dh1", W, 3 * W, "plain"), ("dfc1->dh2", W, 4 * W, "plain"), ("proj fwd", W, W, "bias+res"),
-         ("dfc2->dpre", 4 * W, W, "actgrad")]
+         ("dfc2->dpre", 4 * W, W, "actgrad"), ("dproj->da", W, W, "plain-force"), ("clipproj", 512, W, "plain-force")]
 lefts = [int(v) for v in a.left.split(",")]
 # variants: (label, register epilogue?, split leftover, forced tile)
 variants = [("lds", 0, 0, 0), ("lds+split", 0, 128, 0), ("reg", 1, 0, 0), ("reg+split", 1, 128, 0)]
@@ -57,6 +57,8 @@ for name, n, k, epi in cases:
                  pre_out=pre, act_grad_pre=gpre, act_grad_kind=ACT_QUICKGELU if gpre is not None else 0)
 
     vs = list(variants)
+    if epi == "plain-force":                              # short-K products the heuristic gives to the 128^2 kernel
+        vs = [("128^2", 1, 0, 1282), ("256^2 reg", 1, 0, 2566)]
     if epi == "actgrad":                                  # the dispatcher's default for this epilogue is the 128^2 kernel
         vs = [("128^2 (default)", 1, 0, 0), ("256^2 lds", 0, 0, 2566), ("256^2 reg", 1, 0, 2566)]
 
