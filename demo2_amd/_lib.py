@@ -52,6 +52,9 @@ PROTOTYPES = {
     "demo_gemm_set_pp_min_fill": [C.c_int],
     "demo_cast_f32_bf16": [_P, _P, _L, _P],
     "demo_cast_bf16_f32": [_P, _P, _L, _P],
+    "demo_droppath_mask": [_P, _I, _F, _U64, _P, _P],
+    "demo_rowscale_add": [_P, _P, _I, _P, _P, _I, _I, _I, _P],
+    "demo_rowscale_cast": [_P, _P, _P, _I, _I, _I, _I, _P],
     "demo_transpose": [_P, _P, _I, _I, _I, _P],
     "demo_transpose_batched": [_P, _P, _I, _I, _I, _L, _L, _I, _P],
     "demo_colsum": [_P, _P, _I, _I, _L, _I, _I, _P],

@@ -136,6 +136,44 @@ __global__ __launch_bounds__(256) void get_token0_kernel(const T* __restrict__ t
     *reinterpret_cast<float4*>(out + (int64_t)b * ld + c4 * 4) = io<T>::ld4(tok + (int64_t)b * L * C + c4 * 4);
 }
 
+// ---- DropPath / stochastic depth of the ImageNet ViT blocks (backbones/vit_pytorch.py:48-65,186-187) ----------------------------
+// scale[b] = floor(keep + u_b) / keep, u_b uniform in [0,1) from a counter hash of (seed, b): 0 or 1/keep per image and branch
+__device__ __forceinline__ uint32_t dp_hash(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ULL * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return (uint32_t)((z ^ (z >> 31)) >> 32);
+}
+__global__ __launch_bounds__(256) void droppath_mask_kernel(float* __restrict__ scale, int n, float keep, uint64_t seed,
+                                                            const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev) seed += *seed_dev;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float u = (float)(dp_hash(seed, (uint64_t)i) >> 8) * (1.0f / 16777216.0f);
+  scale[i] = floorf(keep + u) / keep;
+}
+// out[r, :] = x[r, :] + scale[r / L] * t[r, :]      (x, out fp32; t in the compute dtype; out may alias x)
+template <typename T>
+__global__ __launch_bounds__(256) void rowscale_add_kernel(const float* __restrict__ x, const T* __restrict__ t, const float* __restrict__ scale,
+                                                           float* __restrict__ out, int64_t n4, int W4, int L) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float s = scale[(i / W4) / L];
+    const float4 a = *reinterpret_cast<const float4*>(x + i * 4);
+    const float4 b = io<T>::ld4(t + i * 4);
+    *reinterpret_cast<float4*>(out + i * 4) = make_float4(fmaf(s, b.x, a.x), fmaf(s, b.y, a.y), fmaf(s, b.z, a.z), fmaf(s, b.w, a.w));
+  }
+}
+// out[r, :] = scale[r / L] * x[r, :]   (x fp32 -> out in the compute dtype): the branch gradient of a DropPath residual add
+template <typename T>
+__global__ __launch_bounds__(256) void rowscale_cast_kernel(const float* __restrict__ x, const float* __restrict__ scale, T* __restrict__ out,
+                                                            int64_t n4, int W4, int L) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float s = scale[(i / W4) / L];
+    const float4 a = *reinterpret_cast<const float4*>(x + i * 4);
+    io<T>::st4(out + i * 4, make_float4(s * a.x, s * a.y, s * a.z, s * a.w));
+  }
+}
+
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n4, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
     io<bf16_t>::st4(dst + i * 4, *reinterpret_cast<const float4*>(src + i * 4));
@@ -255,6 +293,33 @@ extern "C" int demo_cast_f32_bf16(const float* src, void* dst, int64_t n, void* 
   DEMO_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0, "demo_cast_f32_bf16: misaligned");
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n / 4, n);
   DEMO_LAUNCH_CHECK("demo_cast_f32_bf16");
+  return 0;
+}
+extern "C" int demo_droppath_mask(float* scale, int32_t n, float keep_prob, uint64_t seed, const uint64_t* seed_dev, void* stream) {
+  DEMO_REQUIRE(scale && n > 0 && keep_prob > 0.f && keep_prob <= 1.f, "demo_droppath_mask: n=%d keep=%f", n, keep_prob);
+  hipLaunchKernelGGL(droppath_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scale, n, keep_prob, seed, seed_dev);
+  DEMO_LAUNCH_CHECK("demo_droppath_mask");
+  return 0;
+}
+extern "C" int demo_rowscale_add(const float* x, const void* t, int32_t dt, const float* scale, float* out, int32_t Bn, int32_t L, int32_t W,
+                                 void* stream) {
+  DEMO_REQUIRE(x && t && scale && out && Bn > 0 && L > 0 && W > 0 && W % 4 == 0, "demo_rowscale_add: bad operand");
+  const int64_t n4 = (int64_t)Bn * L * W / 4;
+  if (dt == DEMO_BF16)
+    hipLaunchKernelGGL(rowscale_add_kernel<bf16_t>, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)t, scale, out, n4, W / 4, L);
+  else
+    hipLaunchKernelGGL(rowscale_add_kernel<float>, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, x, (const float*)t, scale, out, n4, W / 4, L);
+  DEMO_LAUNCH_CHECK("demo_rowscale_add");
+  return 0;
+}
+extern "C" int demo_rowscale_cast(const float* x, const float* scale, void* out, int32_t dt, int32_t Bn, int32_t L, int32_t W, void* stream) {
+  DEMO_REQUIRE(x && scale && out && Bn > 0 && L > 0 && W > 0 && W % 4 == 0, "demo_rowscale_cast: bad operand");
+  const int64_t n4 = (int64_t)Bn * L * W / 4;
+  if (dt == DEMO_BF16)
+    hipLaunchKernelGGL(rowscale_cast_kernel<bf16_t>, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, (bf16_t*)out, n4, W / 4, L);
+  else
+    hipLaunchKernelGGL(rowscale_cast_kernel<float>, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, x, scale, (float*)out, n4, W / 4, L);
+  DEMO_LAUNCH_CHECK("demo_rowscale_cast");
   return 0;
 }
 extern "C" int demo_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream) {

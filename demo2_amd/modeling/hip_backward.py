@@ -42,7 +42,7 @@ def train_forward(m, imgs: List[torch.Tensor], cam: Optional[torch.Tensor]):
     B = imgs[0].shape[0]
     tape.d["B"] = B
     T = m.compute_dtype
-    tokens = HF.trunk_forward(m, imgs, cam, T, (), tape)
+    tokens = HF.trunk_forward(m, imgs, cam, T, (), tape, drop_path=True)
     if m.USE_DGAF:
         feat = HF.dgaf_forward(m, tokens, B, tape)
         outs = m._train_outputs_dgaf(feat, None if m.direct else HF.cls_globals(m, tokens, B), tape)
@@ -452,8 +452,11 @@ def trunk_backward(m, tape, dtokens):
     for i in reversed(range(g.layers)):
         k, s = g.block_keys(i), tape.blocks[i]
         d_res = dxbs[cur] if lp else dx                             # gradient of the block output, GEMM operand dtype
-        # x2 = x1 + fc2(u)
-        dw(d_res, s["u"], k["fc2_w"], 4 * W, k["fc2_b"], buf=cur)
+        rbuf = cur
+        if s.get("dp_m") is not None:                               # DropPath: the branch sees scale[image] * gradient
+            d_res, rbuf = ops.rowscale_cast(dx, s["dp_m"], Bn, L, T), None
+        # x2 = x1 + drop_path(fc2(u))
+        dw(d_res, s["u"], k["fc2_w"], 4 * W, k["fc2_b"], buf=rbuf)
         dpre = ops.gemm(d_res, P.wt(k["fc2_w"], T), act_grad_pre=s["pre"], act_grad_kind=act)      # (M, 4W) = (dx W2) * act'(pre)
         # u = act(fc1(h2))
         dw(dpre, s["h2"], k["fc1_w"], W, k["fc1_b"])
@@ -462,8 +465,11 @@ def trunk_backward(m, tape, dtokens):
         ops.layernorm_bwd(dh2, s["x1"], P.f(k["ln2"] + ".weight"), s["mean2"], s["rstd2"], dx=dx, accumulate_dx=True,
                           dw=gw(k["ln2"] + ".weight"), db=gw(k["ln2"] + ".bias"), dx_lp=nb)
         d_res = nb if lp else dx
-        # x1 = x + out_proj(a)
-        dw(d_res, s["a"], k["proj_w"], W, k["proj_b"], buf=cur)
+        rbuf = cur
+        if s.get("dp_a") is not None:
+            d_res, rbuf = ops.rowscale_cast(dx, s["dp_a"], Bn, L, T), None
+        # x1 = x + drop_path(out_proj(a))
+        dw(d_res, s["a"], k["proj_w"], W, k["proj_b"], buf=rbuf)
         da = ops.gemm(d_res, P.wt(k["proj_w"], T))                                                 # (M, W)
         dqkv = ops.attention_bwd(s["qkv"], s["a"], da, s["lse"], Bn, L, g.heads)                   # (M, 3W)
         dw(dqkv, s["h1"], k["qkv_w"], W, k["qkv_b"])

@@ -35,9 +35,14 @@ class Tape:
         self.d: Dict[str, object] = {}
 
 
-def trunk_forward(m, imgs: List[Tensor], cam: Optional[Tensor], T: torch.dtype, zero_mod=(), tape: Optional[Tape] = None) -> Tensor:
+def trunk_forward(m, imgs: List[Tensor], cam: Optional[Tensor], T: torch.dtype, zero_mod=(), tape: Optional[Tape] = None,
+                  drop_path: bool = False) -> Tensor:
     """Shared trunk over [RGB; NI; TI].  Returns tokens (3B*L, C) in dtype T.
-    CLIP: clip/model.py:446-484 + forward_ori :227-230.  ViT: vit_pytorch.py:415-434,173-190."""
+    CLIP: clip/model.py:446-484 + forward_ori :227-230.  ViT: vit_pytorch.py:415-434,173-190.
+    drop_path (training): the ViT blocks' stochastic depth, x + scale[image] * f(x) with scale in {0, 1/keep} per image and branch
+    (vit_pytorch.py:48-65,186-187; rates linspace(0, DROP_PATH, depth), :393).  The masks come from the library's counter RNG (they
+    cannot match torch's stream; m.last_drop_path keeps them so a test can feed them to the oracle).  Such a block's residual
+    add is a separate row-scaling launch instead of the GEMM epilogue: config V only, not the benchmarked path."""
     g = m.geom
     B = imgs[0].shape[0]
     Bn, np_, L, W = 3 * B, g.n_patches, g.n_patches + 1, g.width
@@ -64,16 +69,28 @@ def trunk_forward(m, imgs: List[Tensor], cam: Optional[Tensor], T: torch.dtype, 
     else:
         x = emb
     act = ACT_QUICKGELU if g.arch == "clip" else ACT_GELU
+    rates = g.drop_path if (drop_path and g.drop_path) else None
+    m.last_drop_path = [] if rates else None
     # ---- K3-K6: transformer blocks -------------------------------------------------------------------
     for i in range(g.layers):
         k = g.block_keys(i)
         sv = tape is not None
+        dp = rates[i] if rates else 0.0
+        dp_a = dp_m = None
+        if dp > 0.0:
+            dp_a = ops.droppath_mask(Bn, 1.0 - dp, m.next_seed(), dev, m.seed_dev)
+            dp_m = ops.droppath_mask(Bn, 1.0 - dp, m.next_seed(), dev, m.seed_dev)
+        if rates:
+            m.last_drop_path.append((dp_a, dp_m))
         r1 = ops.layernorm_fwd(x, P.f(k["ln1"] + ".weight"), P.f(k["ln1"] + ".bias"), g.ln_eps, T, save=sv)
         h1 = r1[0] if sv else r1
         qkv = ops.gemm(h1, P.w(k["qkv_w"], T), bias=P.f(k["qkv_b"]))
         r2 = ops.attention_fwd(qkv, Bn, L, g.heads, save_lse=sv)
         a = r2[0] if sv else r2
-        x1 = ops.gemm(a, P.w(k["proj_w"], T), bias=P.f(k["proj_b"]), residual=x, out=None if sv else x, out_dtype=torch.float32)
+        if dp_a is None:
+            x1 = ops.gemm(a, P.w(k["proj_w"], T), bias=P.f(k["proj_b"]), residual=x, out=None if sv else x, out_dtype=torch.float32)
+        else:
+            x1 = ops.rowscale_add(x, ops.gemm(a, P.w(k["proj_w"], T), bias=P.f(k["proj_b"])), dp_a, Bn, L, out=None if sv else x)
         r3 = ops.layernorm_fwd(x1, P.f(k["ln2"] + ".weight"), P.f(k["ln2"] + ".bias"), g.ln_eps, T, save=sv)
         h2 = r3[0] if sv else r3
         if sv:
@@ -82,10 +99,13 @@ def trunk_forward(m, imgs: List[Tensor], cam: Optional[Tensor], T: torch.dtype, 
         else:
             pre = None
             u = ops.gemm(h2, P.w(k["fc1_w"], T), bias=P.f(k["fc1_b"]), act=act)
-        x2 = ops.gemm(u, P.w(k["fc2_w"], T), bias=P.f(k["fc2_b"]), residual=x1, out=None if sv else x1, out_dtype=torch.float32)
+        if dp_m is None:
+            x2 = ops.gemm(u, P.w(k["fc2_w"], T), bias=P.f(k["fc2_b"]), residual=x1, out=None if sv else x1, out_dtype=torch.float32)
+        else:
+            x2 = ops.rowscale_add(x1, ops.gemm(u, P.w(k["fc2_w"], T), bias=P.f(k["fc2_b"])), dp_m, Bn, L, out=None if sv else x1)
         if sv:
             tape.blocks.append(dict(x=x, mean1=r1[1], rstd1=r1[2], h1=h1, qkv=qkv, lse=r2[1], a=a, x1=x1, mean2=r3[1], rstd2=r3[2],
-                                    h2=h2, pre=pre, u=u))
+                                    h2=h2, pre=pre, u=u, dp_a=dp_a, dp_m=dp_m))
         x = x2
     # ---- K7: final LayerNorm (+ CLIP projection) ---------------------------------------------------------
     sv = tape is not None

@@ -191,6 +191,7 @@ class DeMo(_Holder):
         g.dgaf_heads = int(getattr(cfg.MODEL, "DGAF_NUM_HEADS", 8))
         g.dgaf_tau = float(getattr(cfg.MODEL, "DGAF_TAU", 1.0))
         g.bn_eps, g.bn_momentum = 1e-5, 0.1
+        g.drop_path = None                                              # CLIP blocks have none (clip/model.py:227-230)
         g.sie_coe = float(cfg.MODEL.SIE_COE)
         p = "BACKBONE.base."
         if g.arch == "clip":
@@ -217,6 +218,7 @@ class DeMo(_Holder):
             g.cam_embed = p + "sie_embed" if hasattr(base, "sie_embed") else None
             g.cam_all_tokens = True
             g.sie_coe = float(base.sie_xishu)
+            g.drop_path = [float(r) for r in base.drop_path_rates]      # stochastic depth per block, training only (vit_pytorch.py:393)
 
             def block_keys(i, p=p):
                 q = f"{p}blocks.{i}."
@@ -436,7 +438,7 @@ class DeMo(_Holder):
     def _forward_nograd(self, imgs, cam, zero_mod, return_pattern, training=None):
         training = self.training if training is None else training
         B = imgs[0].shape[0]
-        tokens = HF.trunk_forward(self, imgs, cam, self.compute_dtype, zero_mod)
+        tokens = HF.trunk_forward(self, imgs, cam, self.compute_dtype, zero_mod, drop_path=training)
         if self.USE_DGAF:                                                # class DeMo, DGAF-only branch (make_model.py:835-865)
             feat = HF.dgaf_forward(self, tokens, B)
             if not training:

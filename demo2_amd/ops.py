@@ -132,6 +132,35 @@ def cast_bf16_f32(src: Tensor, dst: Tensor):
     return dst
 
 
+def droppath_mask(n: int, keep_prob: float, seed: int, device, seed_dev: Optional[Tensor] = None) -> Tensor:
+    """(n,) fp32: 0 or 1/keep_prob per image (vit_pytorch.py:48-65), from the library's counter RNG."""
+    out = torch.empty(n, device=device, dtype=torch.float32)
+    _req_cuda(out)
+    check(_lib.load().demo_droppath_mask(out.data_ptr(), n, float(keep_prob), seed & (2 ** 64 - 1), _ptr(seed_dev), _stream()), "demo_droppath_mask")
+    return out
+
+
+def rowscale_add(x: Tensor, t: Tensor, scale: Tensor, Bn: int, L: int, out: Optional[Tensor] = None) -> Tensor:
+    """out = x + scale[image] * t   (x, out (Bn*L, W) fp32; t compute dtype)"""
+    _req_cuda(x, t, scale)
+    W = x.shape[1]
+    assert x.dtype == torch.float32 and x.is_contiguous() and t.is_contiguous() and t.shape == x.shape == (Bn * L, W) and scale.numel() == Bn
+    out = torch.empty_like(x) if out is None else out
+    check(_lib.load().demo_rowscale_add(x.data_ptr(), t.data_ptr(), dt_code(t.dtype), scale.data_ptr(), out.data_ptr(), Bn, L, W, _stream()),
+          "demo_rowscale_add")
+    return out
+
+
+def rowscale_cast(x: Tensor, scale: Tensor, Bn: int, L: int, dtype: torch.dtype) -> Tensor:
+    """out = scale[image] * x   ((Bn*L, W) fp32 -> dtype)"""
+    _req_cuda(x, scale)
+    W = x.shape[1]
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape == (Bn * L, W) and scale.numel() == Bn
+    out = torch.empty(Bn * L, W, device=x.device, dtype=dtype)
+    check(_lib.load().demo_rowscale_cast(x.data_ptr(), scale.data_ptr(), out.data_ptr(), dt_code(dtype), Bn, L, W, _stream()), "demo_rowscale_cast")
+    return out
+
+
 def transpose(src: Tensor, dst: Optional[Tensor] = None) -> Tensor:
     _req_cuda(src)
     assert src.dim() == 2 and src.is_contiguous()

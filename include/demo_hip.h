@@ -79,6 +79,13 @@ int demo_gemm_desc_size(void); /* sizeof(demo_gemm_desc): lets a foreign binding
 /* ---- elementwise / layout ----------------------------------------------------------------- */
 /* fp32 -> bf16 shadow copy of the flat parameter buffer (one launch per optimizer step). */
 int demo_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* DropPath / stochastic depth of the ImageNet ViT blocks in training (backbones/vit_pytorch.py:48-65,186-187: x + drop_path(f(x))).
+ * demo_droppath_mask: scale[b] = floor(keep + u_b) / keep (0 or 1/keep per image), u_b from a counter hash of (seed [+ *seed_dev], b);
+ * demo_rowscale_add: out[r,:] = x[r,:] + scale[r / L] * t[r,:] (x, out fp32, may alias; t in dtype dt) -- the residual add;
+ * demo_rowscale_cast: out[r,:] = scale[r / L] * x[r,:] (fp32 -> dt) -- the branch's incoming gradient. */
+int demo_droppath_mask(float* scale, int32_t n, float keep_prob, uint64_t seed, const uint64_t* seed_dev, void* stream);
+int demo_rowscale_add(const float* x, const void* t, int32_t dt, const float* scale, float* out, int32_t Bn, int32_t L, int32_t W, void* stream);
+int demo_rowscale_cast(const float* x, const float* scale, void* out, int32_t dt, int32_t Bn, int32_t L, int32_t W, void* stream);
 int demo_cast_bf16_f32(const void* src, float* dst, int64_t n, void* stream);
 /* 2-D transpose with dtype preserved: dst[c, r] = src[r, c]; used for weight^T shadows (backward). */
 int demo_transpose(const void* src, void* dst, int32_t rows, int32_t cols, int32_t dt, void* stream);

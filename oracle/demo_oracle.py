@@ -170,11 +170,12 @@ def clip_visual(sd: SD, p: str, img: Tensor, cv_emb: Optional[Tensor], spec: Spe
 
 
 def vit_visual(sd: SD, p: str, img: Tensor, cam_label: Optional[Tensor], spec: Spec,
-               taps: Optional[dict] = None) -> Tensor:
+               taps: Optional[dict] = None, drop_scales=None) -> Tensor:
     """ImageNet ViT-B `Trans.forward_features` in eval mode (vit_pytorch.py:415-434):
     conv patch-embed with bias, cls + pos + SIE on *all* tokens (:423-424), 12 pre-LN
-    blocks with erf-GELU (:173-190,125-141), final LayerNorm eps 1e-6.  DropPath /
-    dropout are identity in eval and at the rates the configs use for dropout (0)."""
+    blocks with erf-GELU (:173-190,125-141), final LayerNorm eps 1e-6.  Dropout is identity at the rates the configs use
+    (0).  DropPath (:48-65,186-187) is identity in eval; in training `drop_scales[i] = (s_attn (B,), s_mlp (B,))` holds block i's
+    per-sample factors floor(keep + u) / keep in {0, 1/keep} (None = kept), so that a given mask can be replayed."""
     B = img.shape[0]
     w = sd[p + "patch_embed.proj.weight"]
     x = patchify(img, spec) @ w.reshape(w.shape[0], -1).t() + sd[p + "patch_embed.proj.bias"]
@@ -184,18 +185,21 @@ def vit_visual(sd: SD, p: str, img: Tensor, cam_label: Optional[Tensor], spec: S
         x = x + spec.sie_coe * sd[p + "sie_embed"][cam_label]        # (B,1,D) broadcast over tokens
     for i in range(spec.layers):
         q = f"{p}blocks.{i}."
+        sa, sm = drop_scales[i] if drop_scales is not None else (None, None)
         h = layer_norm(x, sd[q + "norm1.weight"], sd[q + "norm1.bias"], spec.ln_eps)
-        x = x + mha_self(h, sd[q + "attn.qkv.weight"], sd[q + "attn.qkv.bias"],
-                         sd[q + "attn.proj.weight"], sd[q + "attn.proj.bias"], spec.heads)
+        br = mha_self(h, sd[q + "attn.qkv.weight"], sd[q + "attn.qkv.bias"],
+                      sd[q + "attn.proj.weight"], sd[q + "attn.proj.bias"], spec.heads)
+        x = x + (br if sa is None else br * sa[:, None, None])
         h = layer_norm(x, sd[q + "norm2.weight"], sd[q + "norm2.bias"], spec.ln_eps)
         h = F.gelu(linear(h, sd[q + "mlp.fc1.weight"], sd[q + "mlp.fc1.bias"]))
-        x = x + linear(h, sd[q + "mlp.fc2.weight"], sd[q + "mlp.fc2.bias"])
+        br = linear(h, sd[q + "mlp.fc2.weight"], sd[q + "mlp.fc2.bias"])
+        x = x + (br if sm is None else br * sm[:, None, None])
         if taps is not None:
             taps[f"block{i}"] = x
     return layer_norm(x, sd[p + "norm.weight"], sd[p + "norm.bias"], spec.ln_eps)
 
 
-def backbone(sd: SD, img: Tensor, cam_label: Optional[Tensor], spec: Spec) -> Tuple[Tensor, Tensor]:
+def backbone(sd: SD, img: Tensor, cam_label: Optional[Tensor], spec: Spec, drop_scales=None) -> Tuple[Tensor, Tensor]:
     """build_transformer.forward (meta_arch.py:91-103): -> (patch tokens (B,n,C), cls (B,C))."""
     if spec.arch == "clip":
         cv = None
@@ -203,7 +207,7 @@ def backbone(sd: SD, img: Tensor, cam_label: Optional[Tensor], spec: Spec) -> Tu
             cv = spec.sie_coe * sd["BACKBONE.cv_embed"][cam_label]    # :95-97
         x = clip_visual(sd, "BACKBONE.base.", img, cv, spec)
     else:
-        x = vit_visual(sd, "BACKBONE.base.", img, cam_label, spec)
+        x = vit_visual(sd, "BACKBONE.base.", img, cam_label, spec, drop_scales=drop_scales)
     return x[:, 1:], x[:, 0]
 
 
@@ -336,8 +340,9 @@ def bnneck_head(sd: SD, bn: str, cls: str, x: Tensor, spec: Spec, training: bool
 
 def model_forward(sd: SD, spec: Spec, x: Dict[str, Tensor], cam_label: Optional[Tensor] = None,
                   training: bool = False, return_pattern: int = 3, updates: Optional[SD] = None,
-                  drop_masks=None, taps: Optional[dict] = None):
-    """Whole hot path with the wiring of SURVEY.md section 3.2."""
+                  drop_masks=None, taps: Optional[dict] = None, drop_path_scales=None):
+    """Whole hot path with the wiring of SURVEY.md section 3.2.
+    drop_path_scales (ViT trunk, training): per block (s_attn, s_mlp), each (3B,) in the order [RGB | NI | TI] (or None)."""
     imgs = [x["RGB"], x["NI"], x["TI"]]
     if not training:                                                  # make_model.py:233-239
         miss = {"r": (0,), "n": (1,), "t": (2,), "rn": (0, 1), "rt": (0, 2), "nt": (1, 2)}.get(spec.miss, ())
@@ -345,8 +350,12 @@ def model_forward(sd: SD, spec: Spec, x: Dict[str, Tensor], cam_label: Optional[
     if "cam_label" in x:
         cam_label = x["cam_label"]
     caches, globs = [], []
-    for im in imgs:                                                   # :247-249 shared backbone
-        c, g = backbone(sd, im, cam_label, spec)
+    for mi, im in enumerate(imgs):                                    # :247-249 shared backbone
+        B_ = im.shape[0]
+        ds = None
+        if drop_path_scales is not None:
+            ds = [tuple(None if t is None else t[mi * B_:(mi + 1) * B_] for t in pair) for pair in drop_path_scales]
+        c, g = backbone(sd, im, cam_label, spec, ds)
         caches.append(c)
         globs.append(g)
     if spec.use_dgaf:

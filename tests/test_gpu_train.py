@@ -21,6 +21,7 @@ def build(cfg, classes, cams, dtype, seed=0):
     m.load_state_dict(sd)
     m = m.to(DEV).train().set_compute_dtype(dtype)
     m.geom.hdm_dropout = 0.0
+    m.geom.drop_path = None            # ViT stochastic depth off here (its masks come from the kernel RNG): test_vit_drop_path_*
     return m, sd
 
 
@@ -182,3 +183,51 @@ def test_bench_size_gradient_accumulation_is_linear_bf16():
     rel = ((g2 - 2 * g1).norm() / (2 * g1).norm()).item()
     assert rel < 2e-3, rel
     assert int(m._nbt_flat[0]) == 2                                  # every BatchNorm saw two batches
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vit_drop_path_train_step(dtype):
+    """ImageNet-ViT trunk in training: DropPath (vit_pytorch.py:48-65,186-187) with rates linspace(0, DROP_PATH, depth).  The
+    masks come from the library's counter RNG; the ones the step drew are replayed in the oracle, then outputs, loss and every
+    gradient must agree (fp32 mode exactly as the other train tests; bf16 mode loosely)."""
+    cfg = small_cfg("vit", head=2, direct=1, DROP_PATH=0.6, TRUNK_LAYERS=3)
+    torch.manual_seed(0)
+    m = make_model(cfg, 11, 3, 0)
+    sd = O.init_state_dict(spec_of(m), seed=1)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train().set_compute_dtype(dtype)
+    m.geom.hdm_dropout = 0.0
+    assert m.geom.drop_path == pytest.approx([0.0, 0.3, 0.6])
+    spec = spec_of(m)
+    spec.hdm_dropout = 0.0
+    x, cam = synth_batch(8, 64, 32, 3)
+    target = torch.tensor([0, 0, 1, 1, 2, 2, 3, 3])
+    out = m({k: v.to(DEV) for k, v in x.items()}, label=target.to(DEV), cam_label=cam.to(DEV))
+    masks = [tuple(None if t is None else t.cpu() for t in pair) for pair in m.last_drop_path]
+    assert masks[0] == (None, None) and all(t is not None for t in masks[1] + masks[2])
+    vals = torch.cat([t for pair in masks[1:] for t in pair])
+    assert all(v == 0.0 or abs(v - 1 / 0.7) < 1e-6 for v in torch.unique(vals[:48]).tolist())      # block 1: keep 0.7
+    assert 0 < (vals == 0).float().mean() < 1                                                     # some dropped, some kept
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    out_ref = O.model_forward(sdg, spec, x, cam, training=True, updates={}, drop_path_scales=masks)
+    idw, trw = float(cfg.MODEL.ID_LOSS_WEIGHT), float(cfg.MODEL.TRIPLET_LOSS_WEIGHT)
+    loss_ref = O.train_loss(out_ref, target, idw, trw)
+    loss_ref.backward()
+    loss = total_loss(out, target.to(DEV), make_loss_fn(cfg))
+    loss.backward()
+    torch.cuda.synchronize()
+    fp32 = dtype == torch.float32
+    for a, b in zip(out[:-1], out_ref[:-1]):
+        torch.testing.assert_close(a.detach().cpu(), b.detach(), rtol=2e-4 if fp32 else 0.1, atol=2e-4 if fp32 else 0.1)
+    assert abs(loss.item() - loss_ref.item()) < (1e-4 if fp32 else 0.05) * abs(loss_ref.item()) + (1e-4 if fp32 else 0.02)
+    got = {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.requires_grad}
+    errs = {n: rel_err(got[n], v.grad) for n, v in sdg.items() if v.requires_grad and v.grad is not None and n in got and v.grad.norm() > 1e-6}
+    if fp32:
+        bad = {n: e for n, e in errs.items() if e > 2e-3 and (got[n] - sdg[n].grad).abs().max() > 1e-6}
+        assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    else:
+        assert sum(e < 0.2 for e in errs.values()) >= 0.9 * len(errs), sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    # eval mode: identity
+    with torch.no_grad():
+        m.eval()({k: v.to(DEV) for k, v in x.items()}, cam_label=cam.to(DEV))
+    assert m.last_drop_path is None
