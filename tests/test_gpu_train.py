@@ -231,3 +231,82 @@ def test_vit_drop_path_train_step(dtype):
     with torch.no_grad():
         m.eval()({k: v.to(DEV) for k, v in x.items()}, cam_label=cam.to(DEV))
     assert m.last_drop_path is None
+
+
+def test_reference_style_training_loop_matches_oracle_loop():
+    """The loop of engine/processor.py:57-104 as the reference runs it -- its own optimizer construction (solver/make_optimizer.py:
+    per-parameter groups of torch.optim.Adam over model.named_parameters()), optimizer.zero_grad(), autocast + GradScaler,
+    scaler.scale(loss).backward(), scaler.step() -- around the drop-in model, three iterations, against the same loop around
+    the CPU oracle's autograd.  Exercises what a drop-in must survive: set-to-None gradients, in-place parameter updates through
+    views of the flat buffer (the bf16/transposed weight shadows must follow), loss scaling, BatchNorm statistics across steps."""
+    cfg = small_cfg("clip", head=4, direct=1)
+    m, sd = build(cfg, 11, 3, torch.float32)
+    spec = spec_of(m)
+    spec.hdm_dropout = 0.0
+    idw, trw = float(cfg.MODEL.ID_LOSS_WEIGHT), float(cfg.MODEL.TRIPLET_LOSS_WEIGHT)
+    loss_fn = make_loss_fn(cfg)
+
+    def make_optimizer(named):                                      # solver/make_optimizer.py:5-24 with OPTIMIZER_NAME 'Adam'
+        groups = [{"params": [v], "lr": 1e-3, "weight_decay": 1e-4} for _, v in named if v.requires_grad]
+        return torch.optim.Adam(groups)
+
+    opt = make_optimizer(m.named_parameters())
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    ref = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k and not (k.startswith("bottleneck") and k.endswith(".bias")))
+           for k, v in sd.items()}
+    ref_opt = make_optimizer(ref.items())
+    for it in range(3):
+        x, cam = synth_batch(8, 64, 32, 3, seed=100 + it)
+        target = torch.tensor([0, 0, 1, 1, 2, 2, 3, 3])
+        # reference-style step on the device
+        opt.zero_grad()
+        img = {k: v.to(DEV) for k, v in x.items()}
+        with torch.autocast("cuda", enabled=True):
+            out = m(img, label=target.to(DEV), cam_label=cam.to(DEV))
+            loss = total_loss(out, target.to(DEV), loss_fn)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        # the same step on the CPU oracle
+        ref_opt.zero_grad()
+        upd = {}
+        out_ref = O.model_forward(ref, spec, x, cam, training=True, updates=upd)
+        loss_ref = O.train_loss(out_ref, target, idw, trw)
+        loss_ref.backward()
+        ref_opt.step()
+        with torch.no_grad():
+            for k, v in upd.items():
+                ref[k].copy_(v)                                     # BatchNorm running statistics / counters
+        assert abs(loss.item() - loss_ref.item()) < 2e-3 * abs(loss_ref.item()) + 1e-4, (it, loss.item(), loss_ref.item())
+    msd = m.state_dict()
+    worst = max(((msd[k].detach().cpu().float() - v.detach().float()).abs().max().item(), k) for k, v in ref.items() if v.is_floating_point())
+    # Adam moves every element by ~lr per step whatever the gradient's size: elements whose gradient is rounding noise may differ
+    # by a few lr after three steps; everything else agrees closely
+    assert worst[0] < 4e-3, worst
+    diff = torch.cat([(msd[k].detach().cpu().float() - v.detach().float()).abs().reshape(-1) for k, v in ref.items() if v.is_floating_point()])
+    assert (diff > 2e-4).float().mean().item() < 2e-2
+    assert int(msd["bottleneck.num_batches_tracked"]) == 3
+
+
+def test_torch_optimizer_step_refreshes_bf16_shadow():
+    """bf16 mode with a plain torch optimizer (the reference's): the in-place update of the fp32 views must reach the bf16 weight
+    shadow and the transposed copies before the next forward."""
+    cfg = small_cfg("clip")
+    m, _ = build(cfg, 11, 3, torch.bfloat16)
+    opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.05, momentum=0.9)     # make_optimizer.py:19-20
+    x, cam = synth_batch(8, 64, 32, 3)
+    img, target = {k: v.to(DEV) for k, v in x.items()}, torch.tensor([0, 0, 1, 1, 2, 2, 3, 3], device=DEV)
+    loss_fn = make_loss_fn(cfg)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = total_loss(m(img, label=target, cam_label=cam.to(DEV)), target, loss_fn)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+        m.refresh_shadow()
+        P = m.ptab
+        assert torch.equal(P.shadow.float(), P.flat.bfloat16().float())
+        k = m.geom.block_keys(0)["fc1_w"]
+        assert torch.equal(P.wt(k, torch.bfloat16).float(), P.f(k).t().bfloat16().float())
+    assert losses[2] < losses[0]                                    # the same batch three times: the loss goes down
