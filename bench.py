@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--fusion", choices=["atmoe", "dgaf"], default="atmoe",
                     help="atmoe: the headline PIFE -> HDM -> ATMoE model; dgaf: the DeMo class's DGAF-V3 head (SURVEY 8(f) row 3, a side "
                          "measurement, not BASELINE.json's metric)")
+    ap.add_argument("--eager-baseline", action="store_true",
+                    help="also time the torch restatement of the path with PyTorch-ROCm eager on this GPU (bf16 autocast); baseline only")
     ap.add_argument("--host-input", action="store_true",
                     help="train mode: copy each batch from pinned host memory (double-buffered side stream); PCIe-inclusive rate")
     return ap.parse_args()
@@ -187,6 +189,56 @@ def cpu_baseline(mode, seconds, fusion="atmoe"):
                       f"({dt:.1f} s)"}
 
 
+def eager_gpu_baseline(mode, B, dev, steps=5):
+    """Optional second baseline (--eager-baseline; part of the baseline leg, never the product): the same restatement run by
+    PyTorch-ROCm EAGER on this GPU under bf16 autocast (rocBLAS / MIOpen kernels, fused scaled_dot_product_attention in place of
+    the oracle's explicit softmax attention, as the reference's nn.MultiheadAttention would dispatch) -- the closest stand-in for
+    'the reference itself on an MI355X', which cannot travel to the box.  Same batch size as the measured workload."""
+    from oracle import demo_oracle as O
+    from util import synth_batch
+    import torch.nn.functional as F
+    spec = O.Spec()
+    sd = {k: v.to(dev) for k, v in O.init_state_dict(spec, seed=1).items()}
+    if mode == "train":
+        sd = {k: v.requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    x, cam = synth_batch(B, 256, 128, 4, device=dev)
+    target = (torch.arange(B, device=dev) // 4) % 171
+    orig = O.mha_self
+
+    def mha_sdpa(xx, in_w, in_b, out_w, out_b, heads):
+        Bq, L, D = xx.shape
+        qkv = O.linear(xx, in_w, in_b).reshape(Bq, L, 3, heads, D // heads).permute(2, 0, 3, 1, 4)
+        o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(Bq, L, D)
+        return O.linear(o, out_w, out_b)
+
+    O.mha_self = mha_sdpa
+    try:
+        def one():
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                if mode == "train":
+                    out = O.model_forward(sd, spec, x, cam, training=True, updates={})
+                    loss = O.train_loss(out, target)
+                else:
+                    with torch.no_grad():
+                        O.model_forward(sd, spec, x, cam)
+            if mode == "train":
+                loss.backward()
+                for v in sd.values():
+                    v.grad = None
+        for _ in range(2):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        O.mha_self = orig
+    return {"value": round(B / dt, 1), "unit": "triplets/s", "ms_per_step": round(dt * 1e3, 2), "kind": "port, PyTorch-ROCm eager on the GPU",
+            "sample": f"{steps} {'fwd+bwd (no optimizer step)' if mode == 'train' else 'eval forward'} passes at B={B}, bf16 autocast, SDPA attention"}
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -294,7 +346,7 @@ def main():
         dt = float(t.item())
 
     log(f"timed region: {dt:.3f} s for {a.steps} steps")
-    roof = cpu = None
+    roof = cpu = eager = None
     if rank == 0:
         # the instrumented extra step runs on rank 0 ONLY: it must not issue collectives the other ranks never join
         saved_sync = getattr(model, "grad_sync", None)
@@ -306,6 +358,8 @@ def main():
         log("roofline pass done; cpu baseline next")
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(mode, a.cpu_seconds, a.fusion)
+        if world == 1 and a.eager_baseline and a.fusion == "atmoe":
+            eager = eager_gpu_baseline(mode, B, dev)
     if rank == 0:
         ms = dt / a.steps * 1e3
         val = B * world * a.steps / dt
@@ -327,6 +381,8 @@ def main():
             "model_tflops": round(val * flop_per_triplet / 1e12, 1),
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if eager is not None:
+            line["eager_gpu_baseline"] = eager
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
