@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void atmoe_gate_softmax_bwd_kernel(const float
 // backward:  dP_l = dpooled . x_l + dpsum ;  rowdot = sum_l P_l dP_l = dpooled . pooled + dpsum * psum ;
 //            ds_l = P_l dP_l - p_l rowdot ;  dx_l = sum_{br,h} P_l dpooled
 template <typename T>
-__global__ __launch_bounds__(256) void hdm_softmax_pool_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ dpsum,
+__global__ __launch_bounds__(512) void hdm_softmax_pool_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ dpsum,
                                                                    const float* __restrict__ probs, const T* __restrict__ tok,
                                                                    const float* __restrict__ pooled, const float* __restrict__ psum,
                                                                    float* __restrict__ dS, int64_t ldS, float* __restrict__ dtok,
@@ -226,8 +226,8 @@ __global__ __launch_bounds__(256) void hdm_softmax_pool_bwd_kernel(const float* 
     dpl[i] = dpooled[((int64_t)(b * 7 + b_mbranch[m][s]) * Hh) * C + rem];
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = wave; i < 4 * Hh; i += 4) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int i = wave; i < 4 * Hh; i += nw) {
     const int s = i / Hh, h = i - s * Hh;
     const int br = b_mbranch[m][s];
     const float* pl = pooled + ((int64_t)(b * 7 + br) * Hh + h) * C;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void hdm_softmax_pool_bwd_kernel(const float* 
     }
   }
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int l0 = wave * 2; l0 < L; l0 += 8) {          // two tokens per wave per pass: each dpooled row read serves both
+  for (int l0 = wave * 2; l0 < L; l0 += 2 * nw) {     // two tokens per wave per pass: each dpooled row read serves both
     const bool has2 = l0 + 1 < L;
     const int64_t row0 = (int64_t)(m * Bs + b) * L + l0;
     float4 x0[4], x1[4], dx0[4], dx1[4];
@@ -547,10 +547,10 @@ extern "C" int demo_hdm_softmax_pool_bwd(const float* dpooled, const float* dpsu
   if (e != hipSuccess) DEMO_FAIL(-2, "demo_hdm_softmax_pool_bwd: cannot reserve %zu B of LDS: %s", shm, hipGetErrorString(e));
   dim3 grid(Bs, 3);
   if (dt == DEMO_BF16)
-    hipLaunchKernelGGL(hdm_softmax_pool_bwd_kernel<bf16_t>, grid, dim3(256), shm, s, dpooled, dpsum, probs, (const bf16_t*)tokens, pooled,
+    hipLaunchKernelGGL(hdm_softmax_pool_bwd_kernel<bf16_t>, grid, dim3(512), shm, s, dpooled, dpsum, probs, (const bf16_t*)tokens, pooled,
                        psum, dS, ldS, dtokens, Bs, L, C, Hh, p_drop, seed, seed_dev);
   else
-    hipLaunchKernelGGL(hdm_softmax_pool_bwd_kernel<float>, grid, dim3(256), shm, s, dpooled, dpsum, probs, (const float*)tokens, pooled,
+    hipLaunchKernelGGL(hdm_softmax_pool_bwd_kernel<float>, grid, dim3(512), shm, s, dpooled, dpsum, probs, (const float*)tokens, pooled,
                        psum, dS, ldS, dtokens, Bs, L, C, Hh, p_drop, seed, seed_dev);
   DEMO_LAUNCH_CHECK("demo_hdm_softmax_pool_bwd");
   return 0;

@@ -25,7 +25,7 @@ __device__ __forceinline__ uint32_t rng_hash(uint64_t seed, uint64_t idx) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void hdm_softmax_pool_kernel(const float* __restrict__ S, int64_t ldS, const T* __restrict__ tok,
+__global__ __launch_bounds__(512) void hdm_softmax_pool_kernel(const float* __restrict__ S, int64_t ldS, const T* __restrict__ tok,
                                                                float* __restrict__ pooled, float* __restrict__ psum,
                                                                float* __restrict__ probs, float* __restrict__ probs_post, int Bs, int L, int C, int Hh,
                                                                float p_drop, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void hdm_softmax_pool_kernel(const float* __re
   const int ns = c_nstreams[br];
   const int Lk = ns * L, L3 = 3 * L;
   float* P = sm;                              // [Hh][L3]
-  float* red = sm + Hh * L3;                  // [256][4] scratch for the split reduction (reused per head)
+  float* red = sm + Hh * L3;                  // [blockDim][4] scratch for the split reduction (reused per head)
 
   // ---- phase 1: gather scores --------------------------------------------------------------
   for (int i = threadIdx.x; i < Hh * Lk; i += blockDim.x) {
@@ -46,10 +46,10 @@ __global__ __launch_bounds__(256) void hdm_softmax_pool_kernel(const float* __re
   }
   __syncthreads();
   // ---- phase 2: softmax (+dropout) per head, one wave per head -----------------------------------
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   const uint32_t thresh = p_drop > 0.f ? (uint32_t)(p_drop * 4294967296.0) : 0u;
-  for (int h = wave; h < Hh; h += 4) {
+  for (int h = wave; h < Hh; h += nw) {
     float* ph = P + h * L3;
     float m = -INFINITY;
     for (int i = lane; i < Lk; i += 64) m = fmaxf(m, ph[i]);
@@ -176,14 +176,14 @@ extern "C" int demo_hdm_softmax_pool(const float* S, int64_t ldS, const void* to
   DEMO_REQUIRE(C % 4 == 0 && C / 4 <= 256 && C >= 4, "demo_hdm_softmax_pool: C=%d unsupported", C);
   DEMO_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "demo_hdm_softmax_pool: p_drop=%f", p_drop);
   DEMO_REQUIRE(ldS >= 7 * Hh, "demo_hdm_softmax_pool: ldS too small");
-  const size_t shm = sizeof(float) * ((size_t)Hh * 3 * L + 256 * 4);
+  const size_t shm = sizeof(float) * ((size_t)Hh * 3 * L + 512 * 4);
   DEMO_REQUIRE(shm <= 64 * 1024, "demo_hdm_softmax_pool: L=%d too long", L);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(Bs, 7);
   if (dt == DEMO_BF16)
-    hipLaunchKernelGGL(hdm_softmax_pool_kernel<bf16_t>, grid, dim3(256), shm, s, S, ldS, (const bf16_t*)tokens, pooled, psum, probs, probs_post, Bs, L, C, Hh, p_drop, seed, seed_dev);
+    hipLaunchKernelGGL(hdm_softmax_pool_kernel<bf16_t>, grid, dim3(512), shm, s, S, ldS, (const bf16_t*)tokens, pooled, psum, probs, probs_post, Bs, L, C, Hh, p_drop, seed, seed_dev);
   else
-    hipLaunchKernelGGL(hdm_softmax_pool_kernel<float>, grid, dim3(256), shm, s, S, ldS, (const float*)tokens, pooled, psum, probs, probs_post, Bs, L, C, Hh, p_drop, seed, seed_dev);
+    hipLaunchKernelGGL(hdm_softmax_pool_kernel<float>, grid, dim3(512), shm, s, S, ldS, (const float*)tokens, pooled, psum, probs, probs_post, Bs, L, C, Hh, p_drop, seed, seed_dev);
   DEMO_LAUNCH_CHECK("demo_hdm_softmax_pool");
   return 0;
 }
