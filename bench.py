@@ -80,7 +80,9 @@ def gemm_roofline(model, step_fn):
         nbytes = nb * (2 * d.M * d.K + 2 * d.N * d.K + d.M * d.N * szc * (2 if d.pre_out else 1)
                        + (d.M * d.N * 4 if d.residual else 0) + (d.M * d.N * 4 if d.accumulate else 0)
                        + (d.M * d.N * (4 if d.dtPre == _lib.F32 else 2) if d.act_grad_pre else 0))
-        recs[path].append((e0, e1, 2.0 * d.M * d.N * d.K * nb, nbytes))
+        epi = "+".join(t for t, on in (("bias", d.bias), ("act", d.act), ("save_pre", d.pre_out), ("fp32_residual", d.residual),
+                                       ("act_grad", d.act_grad_pre), ("accumulate", d.accumulate)) if on) or "plain"
+        recs[path].append((e0, e1, 2.0 * d.M * d.N * d.K * nb, nbytes, (d.M, d.N, d.K, epi)))
         return rc
 
     class Wrapper:
@@ -124,12 +126,22 @@ def gemm_roofline(model, step_fn):
     stats = {}
     for path, rs in recs.items():
         if rs:
-            ms = sum(a.elapsed_time(b) for a, b, _, _ in rs)
-            fl = sum(f for _, _, f, _ in rs)
+            ms = sum(r[0].elapsed_time(r[1]) for r in rs)
+            fl = sum(r[2] for r in rs)
+            shapes = {}
+            for r in rs:
+                e = shapes.setdefault(r[4], [0, 0.0, 0.0])
+                e[0] += 1
+                e[1] += r[0].elapsed_time(r[1])
+                e[2] += r[2]
             stats[path] = {"kernel": names[path], "launches_per_step": len(rs), "avg_launch_us": round(ms * 1e3 / len(rs), 1),
                            "ms_per_step": round(ms, 3), "algorithmic_gflop_per_step": round(fl / 1e9, 1),
                            "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 1),
-                           "algorithmic_mb_per_launch": round(sum(b for _, _, _, b in rs) / len(rs) / 1e6, 1)}
+                           "algorithmic_mb_per_launch": round(sum(r[3] for r in rs) / len(rs) / 1e6, 1),
+                           # the same launches by product shape and epilogue (rows M of a split product = the part this kernel computes)
+                           "by_shape": [{"M": k[0], "N": k[1], "K": k[2], "epilogue": k[3], "launches_per_step": v[0],
+                                         "avg_launch_us": round(v[1] * 1e3 / v[0], 1), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
+                                        for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][1])[:10]]}
     if not stats:
         return None
     dom = max(stats, key=lambda k: stats[k]["ms_per_step"])
@@ -149,7 +161,7 @@ def gemm_roofline(model, step_fn):
            "unit": "TFLOP/s", "frac": round(s["achieved_tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
            "launches_per_step": s["launches_per_step"], "avg_launch_us": s["avg_launch_us"],
            "gemm_ms_per_step": s["ms_per_step"], "algorithmic_gflop_per_step": s["algorithmic_gflop_per_step"],
-           "algorithmic_mb_per_launch": s["algorithmic_mb_per_launch"]}
+           "algorithmic_mb_per_launch": s["algorithmic_mb_per_launch"], "by_shape": s["by_shape"]}
     other = [v for k, v in stats.items() if k != dom]
     if other:
         out["other_mfma_nt_kernel"] = other[0]
