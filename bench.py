@@ -281,7 +281,9 @@ def main():
     from util import make_cfg, spec_of, synth_batch
     cfg = make_cfg("RGBNT201") if a.fusion == "atmoe" else make_cfg("RGBNT201", HDM=False, ATM=False, USE_DGAF=True)
     torch.manual_seed(1234)
-    model = make_model(cfg, 171, 4, 0)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):     # make_model prints the reference's banner: stdout carries ONLY the JSON line
+        model = make_model(cfg, 171, 4, 0)
     model.load_state_dict(O.init_state_dict(spec_of(model), seed=1))
     model = model.to(dev).set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
     x, cam = synth_batch(B, 256, 128, 4, seed=1234 + rank, device=dev)
