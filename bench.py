@@ -380,7 +380,7 @@ def main():
         # SURVEY.md 8(d), config A (HDM counted unfolded, as the survey does); DGAF head: trunk 68.34 G + 0.05 G folded fusion
         flop_per_triplet = (69.99e9 if a.fusion == "atmoe" else 68.39e9) * (3 if mode == "train" else 1)
         line = {
-            "metric": "tri-modal images/sec " + ("fwd+bwd" if mode == "train" else "fwd"),
+            "metric": "tri-modal images/sec " + ("fwd+bwd" if mode == "train" else "fwd") + " (ViT-B, RGBNT201 shape)",
             "value": round(val, 1), "unit": "triplets/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
