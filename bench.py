@@ -196,7 +196,7 @@ def cpu_baseline(mode, seconds, fusion="atmoe"):
         dt = time.perf_counter() - t0
         if dt >= seconds and n >= 2:
             break
-    return {"value": round(2 * n / dt, 2), "unit": "triplets/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(2 * n / dt, 2), "unit": "tri-modal images/s (1 image = one RGB+NIR+TIR triplet)", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} {'fwd+bwd' if mode == 'train' else 'eval forward'} passes of the fp32 CPU oracle, RGBNT201 " + ("DeMo" if fusion == "atmoe" else "DGAF-V3") + f" config, B=2 "
                       f"({dt:.1f} s)"}
 
@@ -247,7 +247,7 @@ def eager_gpu_baseline(mode, B, dev, steps=5):
         dt = (time.perf_counter() - t0) / steps
     finally:
         O.mha_self = orig
-    return {"value": round(B / dt, 1), "unit": "triplets/s", "ms_per_step": round(dt * 1e3, 2), "kind": "port, PyTorch-ROCm eager on the GPU",
+    return {"value": round(B / dt, 1), "unit": "tri-modal images/s (1 image = one RGB+NIR+TIR triplet)", "ms_per_step": round(dt * 1e3, 2), "kind": "port, PyTorch-ROCm eager on the GPU",
             "sample": f"{steps} {'fwd+bwd (no optimizer step)' if mode == 'train' else 'eval forward'} passes at B={B}, bf16 autocast, SDPA attention"}
 
 
@@ -381,7 +381,7 @@ def main():
         flop_per_triplet = (69.99e9 if a.fusion == "atmoe" else 68.39e9) * (3 if mode == "train" else 1)
         line = {
             "metric": "tri-modal images/sec " + ("fwd+bwd" if mode == "train" else "fwd") + " (ViT-B, RGBNT201 shape)",
-            "value": round(val, 1), "unit": "triplets/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": round(val, 1), "unit": "tri-modal images/s (1 image = one RGB+NIR+TIR triplet)", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": (("RGBNT201 DeMo.yml (CLIP ViT-B/16 x3 + PIFE + HDM + ATMoE), " if a.fusion == "atmoe" else
