@@ -27,25 +27,25 @@ template <int NV> __device__ __forceinline__ void block_sum(float (&v)[NV], floa
   __syncthreads();
 }
 
-// ---- attention pooling, forward: grid (Bs, 3), 256 threads ------------------------------------------------------------------
+// ---- attention pooling, forward: grid (Bs, 3), 512 threads ------------------------------------------------------------------
 // S (3*Bs*L, ldS) fp32: column s*nh + h of the rows of modality s holds the folded score of head h.
 // probs (Bs,3,nh,L-1), pooled (Bs,3,nh,C): pooled[b,s,h,:] = sum_n p[n] tok[(s*Bs+b)*L + 1 + n, :]
 template <typename T>
-__global__ __launch_bounds__(256) void dgaf_attn_pool_kernel(const float* __restrict__ S, int64_t ldS, const T* __restrict__ tok,
+__global__ __launch_bounds__(512) void dgaf_attn_pool_kernel(const float* __restrict__ S, int64_t ldS, const T* __restrict__ tok,
                                                              float* __restrict__ pooled, float* __restrict__ probs, int Bs, int L, int C,
                                                              int nh) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int b = blockIdx.x, s = blockIdx.y, N = L - 1;
   float* P = sm;                               // [nh][N]
-  float* red = sm + nh * N;                    // [256][4]
+  float* red = sm + nh * N;                    // [blockDim][4]
   const int64_t row0 = (int64_t)(s * Bs + b) * L + 1;
-  for (int i = threadIdx.x; i < nh * N; i += 256) {
+  for (int i = threadIdx.x; i < nh * N; i += blockDim.x) {
     const int h = i / N, n = i - h * N;
     P[i] = S[(row0 + n) * ldS + s * nh + h];
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int h = wave; h < nh; h += 4) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int h = wave; h < nh; h += nw) {
     float* ph = P + h * N;
     float m = -INFINITY;
     for (int i = lane; i < N; i += 64) m = fmaxf(m, ph[i]);
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void dgaf_attn_pool_kernel(const float* __rest
     }
   }
   __syncthreads();
-  const int ngroups = C >> 2, nsplit = 256 / ngroups;
+  const int ngroups = C >> 2, nsplit = blockDim.x / ngroups;
   const int grp = threadIdx.x % ngroups, split = threadIdx.x / ngroups;
   float4 acc[NH_MAX];
 #pragma unroll
@@ -102,11 +102,11 @@ __global__ __launch_bounds__(256) void dgaf_attn_pool_kernel(const float* __rest
   }
 }
 
-// ---- attention pooling, backward: grid (Bs, 3), 256 threads; a wave walks tokens ------------------------------------------------
+// ---- attention pooling, backward: grid (Bs, 3), 512 threads; a wave walks tokens ------------------------------------------------
 // dS rows of this (sample, modality) are written over all ldS columns (zeros outside the modality's nh columns and on the
 // cls row); dtok rows likewise (cls row = 0).  sum_m p_m dp_m = dpooled_h . pooled_h, so no second pass over the tokens.
 template <typename T>
-__global__ __launch_bounds__(256) void dgaf_attn_pool_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ pooled,
+__global__ __launch_bounds__(512) void dgaf_attn_pool_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ pooled,
                                                                  const float* __restrict__ probs, const T* __restrict__ tok,
                                                                  float* __restrict__ dS, int64_t ldS, float* __restrict__ dtok, int Bs, int L,
                                                                  int C, int nh) {
@@ -116,11 +116,11 @@ __global__ __launch_bounds__(256) void dgaf_attn_pool_bwd_kernel(const float* __
   float* P = dP + nh * C;                      // [nh][N]
   float* rowdot = P + nh * N;                  // [NH_MAX]
   const int64_t bs = (int64_t)(b * 3 + s);
-  for (int i = threadIdx.x; i < nh * C; i += 256) dP[i] = dpooled[bs * nh * C + i];
-  for (int i = threadIdx.x; i < nh * N; i += 256) P[i] = probs[bs * nh * N + i];
+  for (int i = threadIdx.x; i < nh * C; i += blockDim.x) dP[i] = dpooled[bs * nh * C + i];
+  for (int i = threadIdx.x; i < nh * N; i += blockDim.x) P[i] = probs[bs * nh * N + i];
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int h = wave; h < nh; h += 4) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int h = wave; h < nh; h += nw) {
     float a = 0.f;
     for (int c = lane; c < C; c += 64) a = fmaf(dP[h * C + c], pooled[(bs * nh + h) * C + c], a);
     a = wave_sum(a);
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void dgaf_attn_pool_bwd_kernel(const float* __
   }
   __syncthreads();
   const int64_t rowc = (int64_t)(s * Bs + b) * L;
-  for (int n = wave; n < L; n += 4) {          // n == 0: the cls row (zeros), n >= 1: patch n-1
+  for (int n = wave; n < L; n += nw) {         // n == 0: the cls row (zeros), n >= 1: patch n-1
     float* ds = dS + (rowc + n) * ldS;
     float* dt = dtok + (rowc + n) * C;
     if (n == 0) {
@@ -337,13 +337,13 @@ extern "C" int demo_dgaf_attn_pool(const float* S, int64_t ldS, const void* toke
   DEMO_REQUIRE(nh >= 1 && nh <= NH_MAX, "demo_dgaf_attn_pool: heads=%d unsupported (<=%d)", nh, NH_MAX);
   DEMO_REQUIRE(C % 4 == 0 && C / 4 <= 256 && C >= 4, "demo_dgaf_attn_pool: C=%d unsupported", C);
   DEMO_REQUIRE(ldS >= 3 * nh, "demo_dgaf_attn_pool: ldS too small");
-  const size_t shm = sizeof(float) * ((size_t)nh * (L - 1) + 256 * 4);
+  const size_t shm = sizeof(float) * ((size_t)nh * (L - 1) + 512 * 4);
   DEMO_REQUIRE(shm <= 64 * 1024, "demo_dgaf_attn_pool: L=%d too long", L);
   hipStream_t s = (hipStream_t)stream;
   if (dt == DEMO_BF16)
-    hipLaunchKernelGGL(dgaf_attn_pool_kernel<bf16_t>, dim3(Bs, 3), dim3(256), shm, s, S, ldS, (const bf16_t*)tokens, pooled, probs, Bs, L, C, nh);
+    hipLaunchKernelGGL(dgaf_attn_pool_kernel<bf16_t>, dim3(Bs, 3), dim3(512), shm, s, S, ldS, (const bf16_t*)tokens, pooled, probs, Bs, L, C, nh);
   else
-    hipLaunchKernelGGL(dgaf_attn_pool_kernel<float>, dim3(Bs, 3), dim3(256), shm, s, S, ldS, (const float*)tokens, pooled, probs, Bs, L, C, nh);
+    hipLaunchKernelGGL(dgaf_attn_pool_kernel<float>, dim3(Bs, 3), dim3(512), shm, s, S, ldS, (const float*)tokens, pooled, probs, Bs, L, C, nh);
   DEMO_LAUNCH_CHECK("demo_dgaf_attn_pool");
   return 0;
 }
@@ -359,10 +359,10 @@ extern "C" int demo_dgaf_attn_pool_bwd(const float* dpooled, const float* pooled
   DEMO_REQUIRE(shm <= 64 * 1024, "demo_dgaf_attn_pool_bwd: heads*C=%d too large for LDS", nh * C);
   hipStream_t s = (hipStream_t)stream;
   if (dt == DEMO_BF16)
-    hipLaunchKernelGGL(dgaf_attn_pool_bwd_kernel<bf16_t>, dim3(Bs, 3), dim3(256), shm, s, dpooled, pooled, probs, (const bf16_t*)tokens, dS, ldS,
+    hipLaunchKernelGGL(dgaf_attn_pool_bwd_kernel<bf16_t>, dim3(Bs, 3), dim3(512), shm, s, dpooled, pooled, probs, (const bf16_t*)tokens, dS, ldS,
                        dtokens, Bs, L, C, nh);
   else
-    hipLaunchKernelGGL(dgaf_attn_pool_bwd_kernel<float>, dim3(Bs, 3), dim3(256), shm, s, dpooled, pooled, probs, (const float*)tokens, dS, ldS,
+    hipLaunchKernelGGL(dgaf_attn_pool_bwd_kernel<float>, dim3(Bs, 3), dim3(512), shm, s, dpooled, pooled, probs, (const float*)tokens, dS, ldS,
                        dtokens, Bs, L, C, nh);
   DEMO_LAUNCH_CHECK("demo_dgaf_attn_pool_bwd");
   return 0;
