@@ -151,3 +151,31 @@ def test_dgaf_state_dict_matches_reference_fixture(golden):
         make_model(small_cfg(HDM=False, ATM=False, USE_DGAF=True, DGAF_VERSION="v1"), 11, 3, 0)
     with pytest.raises(NotImplementedError):
         make_model(small_cfg(USE_FRCA=True), 11, 3, 0)
+
+
+def test_checkpoint_round_trip_through_load_param(tmp_path):
+    """engine/processor.py:157-168 saves `model.state_dict()` with torch.save; test_net.py:43 restores it with load_param.  The
+    flat-buffer views must serialise as ordinary per-key tensors and come back into a fresh model's flat buffers."""
+    import torch
+    torch.manual_seed(0)
+    a = make_model(small_cfg(), 11, 3, 0)
+    with torch.no_grad():
+        for p_ in a.parameters():
+            p_.add_(torch.randn_like(p_) * 0.01)                 # (through the views: the alignment gaps of the flat buffer stay zero)
+        for n_, b_ in a.named_buffers():
+            if b_.is_floating_point():
+                b_.add_(0.5)
+        a._nbt_flat += 7
+    path = tmp_path / "DeMo_10.pth"
+    torch.save(a.state_dict(), path)
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    assert all(v.shape == a.state_dict()[k].shape for k, v in sd.items())
+    assert sum(v.numel() for v in sd.values()) < 1.01 * (a.ptab.flat.numel() + a.stab.flat.numel() + a._nbt_flat.numel())   # no whole-buffer copies per key
+    torch.manual_seed(1)
+    b = make_model(small_cfg(), 11, 3, 0)
+    assert not torch.equal(a.ptab.flat, b.ptab.flat)
+    b.load_param(str(path))
+    assert torch.equal(a.ptab.flat, b.ptab.flat) and torch.equal(a.stab.flat, b.stab.flat) and torch.equal(a._nbt_flat, b._nbt_flat)
+    assert int(b.bottleneck.num_batches_tracked) == 7
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
