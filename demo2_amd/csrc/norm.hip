@@ -62,13 +62,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // ~110 VGPRs at R = 4 (4 waves/SIMD; R = 8 at 2 waves/SIMD measures the same); measured loaded-HBM latency is ~5 us, i.e. this kernel lives on bytes in flight.  The two
 // row sums cross the waves through a parity-double-buffered LDS slot (one barrier per chunk).  dw/db are per-thread
 // column accumulators (8 registers, no LDS atomics) stored once per workgroup into the partial-row workspace.
-template <typename TDY, int R, bool ACC>
+// LPS ("low-precision stream", demo_layernorm_bwd_lp): the running residual gradient arrives as bf16 (dres_lp, may be null = none) and
+// only the bf16 result is written -- 380 instead of 608 MB per launch on the trunk's shape, at the price of one bf16 rounding of
+// the gradient stream per LayerNorm instead of one at the end.
+template <typename TDY, int R, bool ACC, bool LPS = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_cols_kernel(const TDY* __restrict__ dy, const float* __restrict__ x,
                                                                  const float* __restrict__ w, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, float* __restrict__ dx,
                                                                  bf16_t* __restrict__ dx_lp, float* __restrict__ dw,
                                                                  float* __restrict__ db, float* __restrict__ part, int M, int D,
-                                                                 int rows_per_block) {
+                                                                 int rows_per_block, const bf16_t* __restrict__ dres_lp = nullptr) {
   typedef typename io<TDY>::raw4 dyraw;
   __shared__ float red[2][R][2][4];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, nw = blockDim.x >> 6;
@@ -96,7 +99,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_cols_kernel(const TDY* __re
       rs[r] = rowok ? rstd[row] : 0.f;
       xv[r] = ok ? *reinterpret_cast<const float4*>((x + o) + c4) : zero4;
       if (ok) dv[r] = io<TDY>::ld4_raw((dy + o) + c4); else dv[r] = dyraw();
-      pv[r] = (ACC && ok) ? *reinterpret_cast<const float4*>((dx + o) + c4) : zero4;
+      if constexpr (LPS) pv[r] = (dres_lp && ok) ? io<bf16_t>::ld4((dres_lp + o) + c4) : zero4;
+      else pv[r] = (ACC && ok) ? *reinterpret_cast<const float4*>((dx + o) + c4) : zero4;
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_cols_kernel(const TDY* __re
         o.z = pv[r].z + rs[r] * (d.z * w4.z - s1 - xh.z * s2);
         o.w = pv[r].w + rs[r] * (d.w * w4.w - s1 - xh.w * s2);
         const int64_t oo = (int64_t)row * D;
-        *reinterpret_cast<float4*>((dx + oo) + c4) = o;
+        if constexpr (!LPS) *reinterpret_cast<float4*>((dx + oo) + c4) = o;
         if (dx_lp) io<bf16_t>::st4((dx_lp + oo) + c4, o);      // bf16 copy = A operand of the next backward GEMM
       }
     }
@@ -475,6 +479,30 @@ extern "C" int demo_layernorm_bwd(const void* dy, int32_t dtDy, const float* x, 
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv64(2 * D, 256), (unsigned)(nblk >= 64 ? 32 : 1)), dim3(256), 0, s, part,
                        nblk, D, dw, db);
     DEMO_LAUNCH_CHECK("demo_layernorm_bwd(reduce)");
+  }
+  return 0;
+}
+
+extern "C" int demo_layernorm_bwd_lp(const void* dy, int32_t dtDy, const float* x, const float* w, const float* mean, const float* rstd,
+                                     const void* dres_bf16, void* dx_bf16, float* dw, float* db, float* workspace, int64_t workspace_elems,
+                                     int32_t M, int32_t D, void* stream) {
+  DEMO_REQUIRE(D % 4 == 0 && D <= 1024, "demo_layernorm_bwd_lp: D=%d unsupported (<= 1024)", D);
+  DEMO_REQUIRE(dy && x && w && mean && rstd && dx_bf16 && M > 0, "demo_layernorm_bwd_lp: null operand");
+  hipStream_t s = (hipStream_t)stream;
+  const int rows_per_block = M >= 16384 ? 32 : 16;
+  const int nblk = (int)cdiv64(M, rows_per_block);
+  float* part = (workspace && workspace_elems >= (int64_t)nblk * 2 * D && (dw || db)) ? workspace : nullptr;
+  const dim3 blk((unsigned)(cdiv64(D, 256) * 64));
+  if (dtDy == DEMO_BF16)
+    hipLaunchKernelGGL((layernorm_bwd_cols_kernel<bf16_t, 4, false, true>), dim3((unsigned)nblk), blk, 0, s, (const bf16_t*)dy, x, w, mean, rstd,
+                       (float*)nullptr, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block, (const bf16_t*)dres_bf16);
+  else
+    hipLaunchKernelGGL((layernorm_bwd_cols_kernel<float, 4, false, true>), dim3((unsigned)nblk), blk, 0, s, (const float*)dy, x, w, mean, rstd,
+                       (float*)nullptr, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block, (const bf16_t*)dres_bf16);
+  DEMO_LAUNCH_CHECK("demo_layernorm_bwd_lp");
+  if (part) {
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv64(2 * D, 256), (unsigned)(nblk >= 64 ? 32 : 1)), dim3(256), 0, s, part, nblk, D, dw, db);
+    DEMO_LAUNCH_CHECK("demo_layernorm_bwd_lp(reduce)");
   }
   return 0;
 }

@@ -407,10 +407,20 @@ def trunk_backward(m, tape, dtokens):
         dy = ops.gemm(dtokens, P.w(g.k_proj, T))                                                   # (3BL, W) = dtokens proj^T
     else:
         dy = dtokens
-    dx = torch.empty(Bn * L, W, device=dev, dtype=torch.float32)
+    # bf16 gradient stream (CLIP trunk, bf16 mode; DEMO_BF16_GRAD_STREAM=0 turns it off): the residual gradient lives only as bf16
+    # between the LayerNorm backwards (demo_layernorm_bwd_lp: 380 instead of 608 MB per launch) -- one rounding per LayerNorm instead
+    # of a fp32 stream rounded once for the GEMMs.  Measured at full size against the fp32 mode (tools/probes/grad_stream_accuracy.py):
+    # per-parameter gradient error median 2.72 % / p90 4.51 % / max 23.5 %, whole gradient 2.68 % -- the same figures to three digits
+    # as with the fp32 stream (2.71 / 4.51 / 23.5 / 2.68): the bf16 operands of the GEMMs set the error, not the stream; 41.2 -> 40.4 ms.
+    lps = bool(lp and m.bf16_grad_stream and g.k_lnpre and not any(b_.get("dp_a") is not None for b_ in tape.blocks if b_))
+    dx = None if lps else torch.empty(Bn * L, W, device=dev, dtype=torch.float32)
     dxb = torch.empty(Bn * L, W, device=dev, dtype=torch.bfloat16) if lp else None
-    ops.layernorm_bwd(dy, t["x_final"], P.f(g.k_lnpost + ".weight"), t["meanf"], t["rstdf"], dx=dx, dw=gw(g.k_lnpost + ".weight"),
-                      db=gw(g.k_lnpost + ".bias"), dx_lp=dxb)
+    if lps:
+        ops.layernorm_bwd_lp(dy, t["x_final"], P.f(g.k_lnpost + ".weight"), t["meanf"], t["rstdf"], None, dxb, dw=gw(g.k_lnpost + ".weight"),
+                             db=gw(g.k_lnpost + ".bias"))
+    else:
+        ops.layernorm_bwd(dy, t["x_final"], P.f(g.k_lnpost + ".weight"), t["meanf"], t["rstdf"], dx=dx, dw=gw(g.k_lnpost + ".weight"),
+                          db=gw(g.k_lnpost + ".bias"), dx_lp=dxb)
     if sync is not None:
         sync.tail_ready()
     # ---- blocks in reverse ---------------------------------------------------------------------------------------------
@@ -461,9 +471,14 @@ def trunk_backward(m, tape, dtokens):
         # u = act(fc1(h2))
         dw(dpre, s["h2"], k["fc1_w"], W, k["fc1_b"])
         dh2 = ops.gemm(dpre, P.wt(k["fc1_w"], T))                                                  # (M, W)
+        prev = dxbs[cur] if lp else None
         nb = next_dxb() if lp else None
-        ops.layernorm_bwd(dh2, s["x1"], P.f(k["ln2"] + ".weight"), s["mean2"], s["rstd2"], dx=dx, accumulate_dx=True,
-                          dw=gw(k["ln2"] + ".weight"), db=gw(k["ln2"] + ".bias"), dx_lp=nb)
+        if lps:
+            ops.layernorm_bwd_lp(dh2, s["x1"], P.f(k["ln2"] + ".weight"), s["mean2"], s["rstd2"], prev, nb, dw=gw(k["ln2"] + ".weight"),
+                                 db=gw(k["ln2"] + ".bias"))
+        else:
+            ops.layernorm_bwd(dh2, s["x1"], P.f(k["ln2"] + ".weight"), s["mean2"], s["rstd2"], dx=dx, accumulate_dx=True,
+                              dw=gw(k["ln2"] + ".weight"), db=gw(k["ln2"] + ".bias"), dx_lp=nb)
         d_res = nb if lp else dx
         rbuf = cur
         if s.get("dp_a") is not None:
@@ -474,9 +489,14 @@ def trunk_backward(m, tape, dtokens):
         dqkv = ops.attention_bwd(s["qkv"], s["a"], da, s["lse"], Bn, L, g.heads)                   # (M, 3W)
         dw(dqkv, s["h1"], k["qkv_w"], W, k["qkv_b"])
         dh1 = ops.gemm(dqkv, P.wt(k["qkv_w"], T))                                                  # (M, W)
+        prev = dxbs[cur] if lp else None
         nb = next_dxb() if lp else None
-        ops.layernorm_bwd(dh1, s["x"], P.f(k["ln1"] + ".weight"), s["mean1"], s["rstd1"], dx=dx, accumulate_dx=True,
-                          dw=gw(k["ln1"] + ".weight"), db=gw(k["ln1"] + ".bias"), dx_lp=nb)
+        if lps:
+            ops.layernorm_bwd_lp(dh1, s["x"], P.f(k["ln1"] + ".weight"), s["mean1"], s["rstd1"], prev, nb, dw=gw(k["ln1"] + ".weight"),
+                                 db=gw(k["ln1"] + ".bias"))
+        else:
+            ops.layernorm_bwd(dh1, s["x"], P.f(k["ln1"] + ".weight"), s["mean1"], s["rstd1"], dx=dx, accumulate_dx=True,
+                              dw=gw(k["ln1"] + ".weight"), db=gw(k["ln1"] + ".bias"), dx_lp=nb)
         tape.blocks[i] = None                                       # release the activations of this block
         if sync is not None:
             if side is not None:
@@ -486,7 +506,7 @@ def trunk_backward(m, tape, dtokens):
         main.wait_stream(side)
     # ---- embedding ----------------------------------------------------------------------------------------------------
     if g.k_lnpre:
-        dpre = ops.layernorm_bwd(dx, t["emb_pre"], P.f(g.k_lnpre + ".weight"), t["emb_mean"], t["emb_rstd"], dw=gw(g.k_lnpre + ".weight"),
+        dpre = ops.layernorm_bwd(dxbs[cur] if lps else dx, t["emb_pre"], P.f(g.k_lnpre + ".weight"), t["emb_mean"], t["emb_rstd"], dw=gw(g.k_lnpre + ".weight"),
                                  db=gw(g.k_lnpre + ".bias"))
     else:
         dpre = dx

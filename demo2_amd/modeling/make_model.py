@@ -169,6 +169,9 @@ class DeMo(_Holder):
         self.grad_sync = None            # set by demo2_amd.dist.GradSync for data-parallel runs
         self.overlap_dw = os.environ.get("DEMO_OVERLAP_DW", "0") == "1"   # opt-in: weight-gradient GEMMs on a side stream (hip_backward.py; measured +1.4 %)
         self._side = None
+        # bf16 mode: the residual GRADIENT stream between the LayerNorm backwards is bf16 (hip_backward.trunk_backward); measured to
+        # change no gradient statistic against the fp32 mode (tools/probes/grad_stream_accuracy.py); DEMO_BF16_GRAD_STREAM=0 restores fp32
+        self.bf16_grad_stream = os.environ.get("DEMO_BF16_GRAD_STREAM", "1") != "0"
         self.geom = self._make_geometry(cfg)
         self._flatten()
 

@@ -285,6 +285,27 @@ def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, 
     return dx
 
 
+def layernorm_bwd_lp(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, dres_lp: Optional[Tensor], out_lp: Tensor,
+                     dw: Optional[Tensor] = None, db: Optional[Tensor] = None) -> Tensor:
+    """out_lp (bf16) = bf16(dres_lp (bf16, optional) + LayerNorm-backward(dy)); dw/db accumulated as in layernorm_bwd."""
+    _req_cuda(dy, x, out_lp)
+    M, D = x.shape
+    assert out_lp.dtype == torch.bfloat16 and out_lp.is_contiguous() and out_lp.shape == x.shape and dy.is_contiguous() and dy.shape == x.shape
+    if dres_lp is not None:
+        assert dres_lp.dtype == torch.bfloat16 and dres_lp.is_contiguous() and dres_lp.shape == x.shape
+    ws, ws_n = None, 0
+    lib = _lib.load()
+    if M >= 1024 and (dw is not None or db is not None):
+        ws_n = int(lib.demo_layernorm_bwd_workspace(M, D))
+        key = (x.device, ws_n)
+        ws = _LN_WS.get(key)
+        if ws is None:
+            ws = _LN_WS[key] = torch.empty(ws_n, device=x.device, dtype=torch.float32)
+    check(lib.demo_layernorm_bwd_lp(dy.data_ptr(), dt_code(dy.dtype), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres_lp),
+                                    out_lp.data_ptr(), _ptr(dw), _ptr(db), _ptr(ws), ws_n, M, D, _stream()), "demo_layernorm_bwd_lp")
+    return out_lp
+
+
 _LN_WS = {}
 _TN_WS = {}        # per device: partial-tile workspace of the two-pass split-K weight-gradient GEMM
 

@@ -126,6 +126,11 @@ int demo_layernorm_bwd(const void* dy, int32_t dtDy, const float* x, const float
 /* workspace (optional, fp32, >= demo_layernorm_bwd_workspace(M, D) elements): per-workgroup dw/db partial rows summed by a
  * second kernel instead of contended global atomics. */
 int64_t demo_layernorm_bwd_workspace(int32_t M, int32_t D);
+/* The same backward with the residual-gradient stream kept in bf16: dx_bf16 = bf16(dres_bf16 (optional) + LayerNorm-backward(dy)); no
+ * fp32 dx is read or written (380 instead of 608 MB per launch at 49536 x 768).  dw/db/workspace as above.  D <= 1024. */
+int demo_layernorm_bwd_lp(const void* dy, int32_t dtDy, const float* x, const float* w, const float* mean, const float* rstd,
+                          const void* dres_bf16, void* dx_bf16, float* dw, float* db, float* workspace, int64_t workspace_elems,
+                          int32_t M, int32_t D, void* stream);
 
 /* BatchNorm1d over x (Bn, F) fp32 (nn.BatchNorm1d at AttnMOE.py:30,53; make_model.py:136,176).
  * training!=0: batch statistics (biased var), running stats updated in place with `momentum`

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Gradient accuracy of the bf16 compute mode with the fp32 / bf16 residual-gradient stream (DEMO_BF16_GRAD_STREAM), config A at
+full size (12 blocks), B = 8, against the same model's own fp32 compute mode (dropout off).  Prints, over all parameters with a
+non-negligible gradient, the norm-relative error: median / 90th / max, and the error of the whole flat gradient."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+from demo2_amd.modeling import make_model  # noqa: E402
+from demo2_amd.modeling.hip_backward import TrainStep  # noqa: E402
+from oracle import demo_oracle as O  # noqa: E402  (seeded weight factory only)
+from util import make_cfg, spec_of, synth_batch  # noqa: E402
+
+cfg = make_cfg("RGBNT201")
+torch.manual_seed(0)
+m = make_model(cfg, 171, 4, 0)
+m.load_state_dict(O.init_state_dict(spec_of(m), seed=1))
+m = m.to("cuda").train()
+m.geom.hdm_dropout = 0.0
+x, cam = synth_batch(8, 256, 128, 4, device="cuda")
+target = torch.tensor([3, 3, 3, 3, 9, 9, 9, 9], device="cuda")
+grads = {}
+for name, dt, lps in (("fp32", torch.float32, False), ("bf16 / fp32 stream", torch.bfloat16, False), ("bf16 / bf16 stream", torch.bfloat16, True)):
+    m.set_compute_dtype(dt)
+    m.bf16_grad_stream = lps
+    ts = TrainStep(m, cfg, 1, optimizer=False)
+    m.grad_buffer().zero_()
+    loss = ts.step(x, target, cam)
+    torch.cuda.synchronize()
+    grads[name] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.requires_grad}
+    print(f"{name:20s} loss {loss.item():.5f}")
+ref = grads["fp32"]
+for name in list(grads)[1:]:
+    errs = []
+    num = den = 0.0
+    for n, g in grads[name].items():
+        r = ref[n]
+        if r.norm() > 1e-6:
+            errs.append(((g - r).norm() / r.norm()).item())
+        num += (g - r).double().pow(2).sum().item()
+        den += r.double().pow(2).sum().item()
+    e = torch.tensor(errs)
+    print(f"{name:20s} per-parameter relative error: median {e.median():.4f}  p90 {e.quantile(0.9):.4f}  max {e.max():.4f}   whole gradient {(num / den) ** 0.5:.4f}")
