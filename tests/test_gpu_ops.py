@@ -190,6 +190,28 @@ def test_layernorm_bwd(M, D):
     torch.testing.assert_close(dx2.cpu(), base + x.grad, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("M,D", [(300, 768), (2500, 768), (37, 128)])
+def test_layernorm_bwd_lp_stream(M, D):
+    """demo_layernorm_bwd_lp: bf16(dres + LayerNorm-backward(dy)) with the running gradient in bf16, no fp32 stream; dw/db as usual;
+    in place (output == running gradient) as the single-stream schedule uses it."""
+    x = (rnd(M, D) + 0.3).requires_grad_(True)
+    w, b = (1 + rnd(D, seed=1, scale=0.1)).requires_grad_(True), rnd(D, seed=2, scale=0.1).requires_grad_(True)
+    dy = rnd(M, D, seed=3).bfloat16()
+    O.layer_norm(x, w, b, 1e-5).backward(dy.float())
+    _, mean, rstd = ops.layernorm_fwd(x.detach().to(DEV), w.detach().to(DEV), b.detach().to(DEV), 1e-5, torch.float32, save=True)
+    res = rnd(M, D, seed=7).bfloat16()
+    dw, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    buf = res.to(DEV).clone()
+    out = ops.layernorm_bwd_lp(dy.to(DEV), x.detach().to(DEV), w.detach().to(DEV), mean, rstd, buf, buf, dw=dw, db=db)
+    assert out.data_ptr() == buf.data_ptr() and out.dtype == torch.bfloat16
+    want = (res.float() + x.grad).bfloat16().float()
+    torch.testing.assert_close(out.float().cpu(), want, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-4, atol=1e-3)
+    out2 = ops.layernorm_bwd_lp(dy.to(DEV), x.detach().to(DEV), w.detach().to(DEV), mean, rstd, None, torch.empty(M, D, device=DEV, dtype=torch.bfloat16))
+    torch.testing.assert_close(out2.float().cpu(), x.grad.bfloat16().float(), rtol=1e-2, atol=1e-2)
+
+
 def test_batchnorm_fwd_plain_and_grouped():
     Bn, Fd = 16, 96
     x, w, b = rnd(Bn, Fd) * 2 + 1, 1 + rnd(Fd, seed=1, scale=0.1), rnd(Fd, seed=2, scale=0.1)
