@@ -63,7 +63,8 @@ PROTOTYPES = {
     "demo_layernorm_fwd": [_P, _P, _P, _F, _P, _I, _P, _P, _I, _I, _P],
     "demo_layernorm_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P],
     "demo_layernorm_bwd_workspace": [_I, _I],
-    "demo_layernorm_bwd_lp": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "demo_layernorm_bwd_lp": [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "demo_layernorm_add_fwd": [_P, _I, _P, _I, _P, _P, _P, _F, _P, _I, _P, _P, _I, _I, _P],
     "demo_adam_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _P, _P],
     "demo_batchnorm_fwd": [_P, _P, _P, _P, _P, _I, _F, _F, _P, _I, _P, _P, _I, _I, _I, _I, _I, _L, _L, _P, _P],
     "demo_attention_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -57,6 +57,70 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
+// Residual add fused into the LayerNorm that follows it (bf16 residual stream of the bf16 mode): s = x (+ add), rounded to the
+// stream's dtype TX FIRST (so that the saved stream, its statistics and y all describe the same values), xsum_out = s (may alias
+// x), y = LN(s).  The branch GEMM (attention projection / fc2) then has a plain bf16 epilogue and the fp32 read-modify-write of the
+// stream in its epilogue disappears: per pair 380 MB instead of 532 MB at 49536 x 768.
+template <typename TX, typename TA, typename TY>
+__global__ __launch_bounds__(256) void layernorm_add_fwd_kernel(const TX* __restrict__ x, const TA* __restrict__ add, TX* __restrict__ xsum_out,
+                                                                const float* __restrict__ w, const float* __restrict__ b, float eps,
+                                                                TY* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                int M, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int64_t ro = (int64_t)row * D;
+  const int nv = D >> 2;
+  float4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      float4 a = io<TX>::ld4(x + ro + c * 4);
+      if (add) {
+        const float4 t = io<TA>::ld4(add + ro + c * 4);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+      }
+      if (sizeof(TX) == 2) {                         // the stream's rounding, applied before anything is derived from the sum
+        a.x = bf2f(f2bf(a.x)); a.y = bf2f(f2bf(a.y)); a.z = bf2f(f2bf(a.z)); a.w = bf2f(f2bf(a.w));
+      }
+      v[i] = a;
+      if (xsum_out) io<TX>::st4(xsum_out + ro + c * 4, a);
+      s += (a.x + a.y) + (a.z + a.w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+      q += (a * a + bb * bb) + (cc * cc + dd * dd);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float4 g = *reinterpret_cast<const float4*>(w + c * 4);
+      const float4 be = *reinterpret_cast<const float4*>(b + c * 4);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + be.x;
+      o.y = (v[i].y - mean) * rstd * g.y + be.y;
+      o.z = (v[i].z - mean) * rstd * g.z + be.z;
+      o.w = (v[i].w - mean) * rstd * g.w + be.w;
+      io<TY>::st4(y + ro + c * 4, o);
+    }
+  }
+}
+
 // Backward, column-owner form (D <= 1024): thread t owns columns 4t..4t+3 and walks the workgroup's rows R at a time.
 // All 3R loads of a chunk (x, dy, running dx) are issued back to back, so a wave keeps R*40 B per lane in flight with
 // ~110 VGPRs at R = 4 (4 waves/SIMD; R = 8 at 2 waves/SIMD measures the same); measured loaded-HBM latency is ~5 us, i.e. this kernel lives on bytes in flight.  The two
@@ -65,8 +129,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // LPS ("low-precision stream", demo_layernorm_bwd_lp): the running residual gradient arrives as bf16 (dres_lp, may be null = none) and
 // only the bf16 result is written -- 380 instead of 608 MB per launch on the trunk's shape, at the price of one bf16 rounding of
 // the gradient stream per LayerNorm instead of one at the end.
-template <typename TDY, int R, bool ACC, bool LPS = false>
-__global__ __launch_bounds__(256) void layernorm_bwd_cols_kernel(const TDY* __restrict__ dy, const float* __restrict__ x,
+template <typename TDY, int R, bool ACC, bool LPS = false, typename TX = float>
+__global__ __launch_bounds__(256) void layernorm_bwd_cols_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x,
                                                                  const float* __restrict__ w, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, float* __restrict__ dx,
                                                                  bf16_t* __restrict__ dx_lp, float* __restrict__ dw,
@@ -97,7 +161,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_cols_kernel(const TDY* __re
       const int64_t o = (int64_t)row * D;               // uniform row base (SGPR pair) + per-thread 32-bit column offset
       mu[r] = rowok ? mean[row] : 0.f;
       rs[r] = rowok ? rstd[row] : 0.f;
-      xv[r] = ok ? *reinterpret_cast<const float4*>((x + o) + c4) : zero4;
+      xv[r] = ok ? io<TX>::ld4((x + o) + c4) : zero4;
       if (ok) dv[r] = io<TDY>::ld4_raw((dy + o) + c4); else dv[r] = dyraw();
       if constexpr (LPS) pv[r] = (dres_lp && ok) ? io<bf16_t>::ld4((dres_lp + o) + c4) : zero4;
       else pv[r] = (ACC && ok) ? *reinterpret_cast<const float4*>((dx + o) + c4) : zero4;
@@ -420,6 +484,23 @@ extern "C" int demo_layernorm_fwd(const float* x, const float* w, const float* b
   return 0;
 }
 
+extern "C" int demo_layernorm_add_fwd(const void* x, int32_t dtX, const void* add, int32_t dtAdd, void* xsum_out, const float* w, const float* b,
+                                      float eps, void* y, int32_t dtY, float* mean, float* rstd, int32_t M, int32_t D, void* stream) {
+  DEMO_REQUIRE(D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "demo_layernorm_add_fwd: D=%d must be a multiple of 4 and <= %d", D, 64 * 4 * LN_MAXV);
+  DEMO_REQUIRE(x && w && b && y && M > 0, "demo_layernorm_add_fwd: null operand");
+  DEMO_REQUIRE(dtY == DEMO_BF16 && (!add || dtAdd == DEMO_BF16), "demo_layernorm_add_fwd: y and add are bf16 (the bf16 compute mode's activations)");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)cdiv64(M, 4));
+  if (dtX == DEMO_BF16)
+    hipLaunchKernelGGL((layernorm_add_fwd_kernel<bf16_t, bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)add, (bf16_t*)xsum_out,
+                       w, b, eps, (bf16_t*)y, mean, rstd, M, D);
+  else
+    hipLaunchKernelGGL((layernorm_add_fwd_kernel<float, bf16_t, bf16_t>), grid, dim3(256), 0, s, (const float*)x, (const bf16_t*)add, (float*)xsum_out,
+                       w, b, eps, (bf16_t*)y, mean, rstd, M, D);
+  DEMO_LAUNCH_CHECK("demo_layernorm_add_fwd");
+  return 0;
+}
+
 extern "C" int demo_layernorm_bwd(const void* dy, int32_t dtDy, const float* x, const float* w, const float* mean,
                                   const float* rstd, float* dx, int32_t accumulate_dx, void* dx_bf16, float* dw, float* db,
                                   float* workspace, int64_t workspace_elems, int32_t M, int32_t D, void* stream) {
@@ -483,7 +564,7 @@ extern "C" int demo_layernorm_bwd(const void* dy, int32_t dtDy, const float* x, 
   return 0;
 }
 
-extern "C" int demo_layernorm_bwd_lp(const void* dy, int32_t dtDy, const float* x, const float* w, const float* mean, const float* rstd,
+extern "C" int demo_layernorm_bwd_lp(const void* dy, int32_t dtDy, const void* x, int32_t dtX, const float* w, const float* mean, const float* rstd,
                                      const void* dres_bf16, void* dx_bf16, float* dw, float* db, float* workspace, int64_t workspace_elems,
                                      int32_t M, int32_t D, void* stream) {
   DEMO_REQUIRE(D % 4 == 0 && D <= 1024, "demo_layernorm_bwd_lp: D=%d unsupported (<= 1024)", D);
@@ -493,12 +574,12 @@ extern "C" int demo_layernorm_bwd_lp(const void* dy, int32_t dtDy, const float* 
   const int nblk = (int)cdiv64(M, rows_per_block);
   float* part = (workspace && workspace_elems >= (int64_t)nblk * 2 * D && (dw || db)) ? workspace : nullptr;
   const dim3 blk((unsigned)(cdiv64(D, 256) * 64));
-  if (dtDy == DEMO_BF16)
-    hipLaunchKernelGGL((layernorm_bwd_cols_kernel<bf16_t, 4, false, true>), dim3((unsigned)nblk), blk, 0, s, (const bf16_t*)dy, x, w, mean, rstd,
-                       (float*)nullptr, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block, (const bf16_t*)dres_bf16);
-  else
-    hipLaunchKernelGGL((layernorm_bwd_cols_kernel<float, 4, false, true>), dim3((unsigned)nblk), blk, 0, s, (const float*)dy, x, w, mean, rstd,
-                       (float*)nullptr, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block, (const bf16_t*)dres_bf16);
+#define LN_LP(TDY_, TX_)                                                                                                               \
+  hipLaunchKernelGGL((layernorm_bwd_cols_kernel<TDY_, 4, false, true, TX_>), dim3((unsigned)nblk), blk, 0, s, (const TDY_*)dy, (const TX_*)x, w, \
+                     mean, rstd, (float*)nullptr, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block, (const bf16_t*)dres_bf16)
+  if (dtDy == DEMO_BF16) { if (dtX == DEMO_BF16) LN_LP(bf16_t, bf16_t); else LN_LP(bf16_t, float); }
+  else { if (dtX == DEMO_BF16) LN_LP(float, bf16_t); else LN_LP(float, float); }
+#undef LN_LP
   DEMO_LAUNCH_CHECK("demo_layernorm_bwd_lp");
   if (part) {
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)cdiv64(2 * D, 256), (unsigned)(nblk >= 64 ? 32 : 1)), dim3(256), 0, s, part, nblk, D, dw, db);

@@ -172,6 +172,8 @@ class DeMo(_Holder):
         # bf16 mode: the residual GRADIENT stream between the LayerNorm backwards is bf16 (hip_backward.trunk_backward); measured to
         # change no gradient statistic against the fp32 mode (tools/probes/grad_stream_accuracy.py); DEMO_BF16_GRAD_STREAM=0 restores fp32
         self.bf16_grad_stream = os.environ.get("DEMO_BF16_GRAD_STREAM", "1") != "0"
+        # bf16 mode, CLIP trunk: the forward residual stream in bf16 with the adds fused into the LayerNorms (hip_forward.py)
+        self.bf16_fwd_stream = os.environ.get("DEMO_BF16_FWD_STREAM", "0") == "1"
         self.geom = self._make_geometry(cfg)
         self._flatten()
 

@@ -285,6 +285,25 @@ def layernorm_bwd(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, 
     return dx
 
 
+def layernorm_add_fwd(x: Tensor, add: Optional[Tensor], w: Tensor, b: Tensor, eps: float, xsum_out: Optional[Tensor] = None, save: bool = False):
+    """s = x (+ add), rounded to x's dtype; xsum_out (optional, may be x itself) = s; -> y = LN(s) in bf16 [, mean, rstd when save]"""
+    _req_cuda(x, add, w, b)
+    assert x.dim() == 2 and x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)
+    M, D = x.shape
+    if add is not None:
+        assert add.dtype == torch.bfloat16 and add.is_contiguous() and add.shape == x.shape
+    if xsum_out is not None:
+        assert xsum_out.dtype == x.dtype and xsum_out.is_contiguous() and xsum_out.shape == x.shape
+    y = torch.empty(M, D, device=x.device, dtype=torch.bfloat16)
+    mean = rstd = None
+    if save:
+        mean = torch.empty(M, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    check(_lib.load().demo_layernorm_add_fwd(x.data_ptr(), dt_code(x.dtype), _ptr(add), BF16, _ptr(xsum_out), w.data_ptr(), b.data_ptr(), float(eps),
+                                             y.data_ptr(), BF16, _ptr(mean), _ptr(rstd), M, D, _stream()), "demo_layernorm_add_fwd")
+    return (y, mean, rstd) if save else y
+
+
 def layernorm_bwd_lp(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tensor, dres_lp: Optional[Tensor], out_lp: Tensor,
                      dw: Optional[Tensor] = None, db: Optional[Tensor] = None) -> Tensor:
     """out_lp (bf16) = bf16(dres_lp (bf16, optional) + LayerNorm-backward(dy)); dw/db accumulated as in layernorm_bwd."""
@@ -301,7 +320,7 @@ def layernorm_bwd_lp(dy: Tensor, x: Tensor, w: Tensor, mean: Tensor, rstd: Tenso
         ws = _LN_WS.get(key)
         if ws is None:
             ws = _LN_WS[key] = torch.empty(ws_n, device=x.device, dtype=torch.float32)
-    check(lib.demo_layernorm_bwd_lp(dy.data_ptr(), dt_code(dy.dtype), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres_lp),
+    check(lib.demo_layernorm_bwd_lp(dy.data_ptr(), dt_code(dy.dtype), x.data_ptr(), dt_code(x.dtype), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres_lp),
                                     out_lp.data_ptr(), _ptr(dw), _ptr(db), _ptr(ws), ws_n, M, D, _stream()), "demo_layernorm_bwd_lp")
     return out_lp
 

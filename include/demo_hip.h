@@ -126,9 +126,13 @@ int demo_layernorm_bwd(const void* dy, int32_t dtDy, const float* x, const float
 /* workspace (optional, fp32, >= demo_layernorm_bwd_workspace(M, D) elements): per-workgroup dw/db partial rows summed by a
  * second kernel instead of contended global atomics. */
 int64_t demo_layernorm_bwd_workspace(int32_t M, int32_t D);
-/* The same backward with the residual-gradient stream kept in bf16: dx_bf16 = bf16(dres_bf16 (optional) + LayerNorm-backward(dy)); no
+/* Residual add fused into the LayerNorm that follows it (x + drop-free branch output, clip/model.py:227-230): s = x (+ add, bf16),
+ * rounded to x's dtype first; xsum_out (optional, x's dtype, may alias x) = s; y (bf16) = LN(s); mean/rstd (optional) of s. */
+int demo_layernorm_add_fwd(const void* x, int32_t dtX, const void* add, int32_t dtAdd, void* xsum_out, const float* w, const float* b,
+                           float eps, void* y, int32_t dtY, float* mean, float* rstd, int32_t M, int32_t D, void* stream);
+/* The same backward with the residual-gradient stream kept in bf16 (x in dtype dtX): dx_bf16 = bf16(dres_bf16 (optional) + LayerNorm-backward(dy)); no
  * fp32 dx is read or written (380 instead of 608 MB per launch at 49536 x 768).  dw/db/workspace as above.  D <= 1024. */
-int demo_layernorm_bwd_lp(const void* dy, int32_t dtDy, const float* x, const float* w, const float* mean, const float* rstd,
+int demo_layernorm_bwd_lp(const void* dy, int32_t dtDy, const void* x, int32_t dtX, const float* w, const float* mean, const float* rstd,
                           const void* dres_bf16, void* dx_bf16, float* dw, float* db, float* workspace, int64_t workspace_elems,
                           int32_t M, int32_t D, void* stream);
 

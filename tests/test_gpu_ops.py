@@ -190,6 +190,29 @@ def test_layernorm_bwd(M, D):
     torch.testing.assert_close(dx2.cpu(), base + x.grad, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("xdt", [torch.bfloat16, torch.float32])
+def test_layernorm_add_fwd(xdt):
+    """demo_layernorm_add_fwd: s = round_to_stream(x + add); xsum_out = s (also in place); y = LN(s) in bf16; statistics of s."""
+    M, D = 259, 768
+    x = (rnd(M, D, scale=2.0) + 0.5).to(xdt)
+    add = rnd(M, D, seed=4).bfloat16()
+    w, b = 1 + rnd(D, seed=1, scale=0.1), rnd(D, seed=2, scale=0.1)
+    ssum = (x.float() + add.float()).to(xdt).float()
+    want = O.layer_norm(ssum, w, b, 1e-5)
+    xs = torch.empty(M, D, device=DEV, dtype=xdt)
+    y, mean, rstd = ops.layernorm_add_fwd(x.to(DEV), add.to(DEV), w.to(DEV), b.to(DEV), 1e-5, xsum_out=xs, save=True)
+    assert y.dtype == torch.bfloat16
+    torch.testing.assert_close(xs.float().cpu(), ssum, rtol=0, atol=0)
+    torch.testing.assert_close(y.float().cpu(), want, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(mean.cpu(), ssum.mean(-1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(rstd.cpu(), (ssum.var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4, atol=1e-5)
+    xin = x.to(DEV).clone()                                      # in place, and without an addend
+    y2 = ops.layernorm_add_fwd(xin, add.to(DEV), w.to(DEV), b.to(DEV), 1e-5, xsum_out=xin)
+    assert torch.equal(xin, xs) and torch.equal(y2, y)
+    y3 = ops.layernorm_add_fwd(x.to(DEV), None, w.to(DEV), b.to(DEV), 1e-5)
+    torch.testing.assert_close(y3.float().cpu(), O.layer_norm(x.float(), w, b, 1e-5), rtol=1e-2, atol=1e-2)
+
+
 @pytest.mark.parametrize("M,D", [(300, 768), (2500, 768), (37, 128)])
 def test_layernorm_bwd_lp_stream(M, D):
     """demo_layernorm_bwd_lp: bf16(dres + LayerNorm-backward(dy)) with the running gradient in bf16, no fp32 stream; dw/db as usual;

@@ -310,3 +310,25 @@ def test_torch_optimizer_step_refreshes_bf16_shadow():
         k = m.geom.block_keys(0)["fc1_w"]
         assert torch.equal(P.wt(k, torch.bfloat16).float(), P.f(k).t().bfloat16().float())
     assert losses[2] < losses[0]                                    # the same batch three times: the loss goes down
+
+
+def test_bf16_forward_stream_option_trains_like_the_default():
+    """DEMO_BF16_FWD_STREAM (opt-in): residual stream in bf16 with the adds fused into the LayerNorms.  Same loss and gradients as the
+    default bf16 mode up to bf16 noise, and the same eval features."""
+    cfg = small_cfg("clip")
+    x, cam = synth_batch(8, 64, 32, 3)
+    xd, camd = {k: v.to(DEV) for k, v in x.items()}, cam.to(DEV)
+    target = torch.tensor([0, 0, 1, 1, 2, 2, 3, 3], device=DEV)
+    res = []
+    for fwd in (False, True):
+        m, _ = build(cfg, 11, 3, torch.bfloat16)
+        m.bf16_fwd_stream = fwd
+        with torch.no_grad():
+            feat = m.eval()(xd, cam_label=camd).cpu()
+        ts = TrainStep(m.train(), cfg, 1, optimizer=False)
+        loss = ts.step(xd, target, camd).item()
+        res.append((feat, loss, m.grad_buffer().detach().cpu().clone()))
+    (f0, l0, g0), (f1, l1, g1) = res
+    assert (f0 - f1).abs().max() < 0.1 and (f0 - f1).norm() / f0.norm() < 0.03
+    assert abs(l0 - l1) < 0.02 * abs(l0) + 0.01
+    assert ((g0 - g1).norm() / g0.norm()).item() < 0.1

@@ -23,9 +23,21 @@ m.geom.hdm_dropout = 0.0
 x, cam = synth_batch(8, 256, 128, 4, device="cuda")
 target = torch.tensor([3, 3, 3, 3, 9, 9, 9, 9], device="cuda")
 grads = {}
-for name, dt, lps in (("fp32", torch.float32, False), ("bf16 / fp32 stream", torch.bfloat16, False), ("bf16 / bf16 stream", torch.bfloat16, True)):
+feats = {}
+VARIANTS = (("fp32", torch.float32, False, False), ("bf16 / fp32 stream", torch.bfloat16, False, False),
+            ("bf16 / bf16 stream", torch.bfloat16, True, False), ("bf16 / bf16 fwd+bwd", torch.bfloat16, True, True))
+for name, dt, lps, fwd in VARIANTS:                       # eval features first: the training steps below move the BatchNorm statistics
+    m.set_compute_dtype(dt)
+    m.bf16_grad_stream, m.bf16_fwd_stream = lps, fwd
+    with torch.no_grad():
+        feats[name] = m.eval()(x, cam_label=cam).float().cpu()
+m.train()
+stats0 = m.stab.flat.clone()
+for name, dt, lps, fwd in VARIANTS:
     m.set_compute_dtype(dt)
     m.bf16_grad_stream = lps
+    m.bf16_fwd_stream = fwd
+    m.stab.flat.copy_(stats0)
     ts = TrainStep(m, cfg, 1, optimizer=False)
     m.grad_buffer().zero_()
     loss = ts.step(x, target, cam)
@@ -43,4 +55,6 @@ for name in list(grads)[1:]:
         num += (g - r).double().pow(2).sum().item()
         den += r.double().pow(2).sum().item()
     e = torch.tensor(errs)
+    fe = (feats[name] - feats["fp32"])
+    print(f"{name:20s} eval features vs fp32 mode: max abs {fe.abs().max():.4f}  relative {fe.norm() / feats['fp32'].norm():.5f}")
     print(f"{name:20s} per-parameter relative error: median {e.median():.4f}  p90 {e.quantile(0.9):.4f}  max {e.max():.4f}   whole gradient {(num / den) ** 0.5:.4f}")
