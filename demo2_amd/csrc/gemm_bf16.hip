@@ -884,8 +884,14 @@ int demo_gemm_bf16_split_rows(const demo_gemm_desc& d) {
   return (int)(tm1 * 256);
 }
 
-int demo_gemm_bf16(const demo_gemm_desc& d, hipStream_t s) {
-  const int m1 = demo_gemm_bf16_split_rows(d);
+// cfg_override: 0 = choose by the heuristic (and split by rows where that pays), otherwise the configuration code to launch.  The two
+// parts of a split product are issued through the override, not through the g_force_tile test hook: the library is entered from two
+// threads (forward on the caller's, backward on autograd's) and must not pass state between calls through a global.
+static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg_override);
+int demo_gemm_bf16(const demo_gemm_desc& d, hipStream_t s) { return demo_gemm_bf16_launch(d, s, 0); }
+
+static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg_override) {
+  const int m1 = cfg_override ? 0 : demo_gemm_bf16_split_rows(d);
   if (m1 > 0) {
     demo_gemm_desc a = d, b = d;
     a.M = m1;
@@ -896,12 +902,8 @@ int demo_gemm_bf16(const demo_gemm_desc& d, hipStream_t s) {
     if (d.residual) b.residual = d.residual + (int64_t)m1 * d.c_rs;
     if (d.act_grad_pre) b.act_grad_pre = (const char*)d.act_grad_pre + (int64_t)m1 * d.c_rs * szP;
     if (d.pre_out) b.pre_out = (char*)d.pre_out + (int64_t)m1 * d.c_rs * szC;
-    const int saved = g_force_tile;
-    g_force_tile = 2566;
-    int rc = demo_gemm_bf16(a, s);
-    g_force_tile = 1282;
-    if (rc == 0) rc = demo_gemm_bf16(b, s);
-    g_force_tile = saved;
+    int rc = demo_gemm_bf16_launch(a, s, 2566);
+    if (rc == 0) rc = demo_gemm_bf16_launch(b, s, 1282);
     return rc;
   }
   FArgs p;
@@ -921,7 +923,7 @@ int demo_gemm_bf16(const demo_gemm_desc& d, hipStream_t s) {
   const int nb = d.batch1 * d.batch2;
   // configuration code = tile*10 + stages: 1282 (128^2, 2 buffers, 2 workgroups/CU), 1283, 1284 (1 workgroup/CU),
   // 2562 (256^2, 8 waves), 2563 = 256x128 with 3 buffers
-  const int cfg = demo_gemm_bf16_config(d);
+  const int cfg = cfg_override ? cfg_override : demo_gemm_bf16_config(d);
 #define LAUNCH(BM_, BN_, WM_, WN_, NS_)                                                                                  \
   do {                                                                                                                   \
     p.ntm = (int)cdiv64(d.M, BM_);                                                                                       \
