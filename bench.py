@@ -22,7 +22,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 B_TRAFFIC_VALID = [False]        # the committed PMC traffic figures describe the default workload only (train step, B=128)
@@ -170,6 +169,7 @@ def gemm_roofline(model, step_fn):
 
 def cpu_baseline(mode, seconds, fusion="atmoe"):
     """The CPU restatement (oracle) on this host's cores, bounded sample of the same workload (B=2 batches)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import demo_oracle as O
     from util import synth_batch
     # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
@@ -206,6 +206,7 @@ def eager_gpu_baseline(mode, B, dev, steps=5):
     PyTorch-ROCm EAGER on this GPU under bf16 autocast (rocBLAS / MIOpen kernels, fused scaled_dot_product_attention in place of
     the oracle's explicit softmax attention, as the reference's nn.MultiheadAttention would dispatch) -- the closest stand-in for
     'the reference itself on an MI355X', which cannot travel to the box.  Same batch size as the measured workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import demo_oracle as O
     from util import synth_batch
     import torch.nn.functional as F
@@ -276,17 +277,22 @@ def main():
     B = a.batch or (128 if mode == "train" else 64)
     B_TRAFFIC_VALID[0] = mode == "train" and B == 128 and a.dtype == "bf16" and a.fusion == "atmoe"
 
+    # the measured path imports nothing from oracle/ (or tests/): configuration, weights (the modules' own seeded random
+    # initialisation -- there are no pretrained files offline) and the synthetic batch are made here
+    from demo2_amd.config import get_defaults
     from demo2_amd.modeling import make_model
-    from oracle import demo_oracle as O      # only for the seeded weight factory + cpu_baseline (checker side)
-    from util import make_cfg, spec_of, synth_batch
-    cfg = make_cfg("RGBNT201") if a.fusion == "atmoe" else make_cfg("RGBNT201", HDM=False, ATM=False, USE_DGAF=True)
+    cfg = get_defaults()
+    cfg.merge_from_file(os.path.join(ROOT, "demo2_amd", "configs", "RGBNT201", "DeMo.yml"))
+    if a.fusion == "dgaf":
+        cfg.MODEL.HDM, cfg.MODEL.ATM, cfg.MODEL.USE_DGAF = False, False, True
     torch.manual_seed(1234)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):     # make_model prints the reference's banner: stdout carries ONLY the JSON line
         model = make_model(cfg, 171, 4, 0)
-    model.load_state_dict(O.init_state_dict(spec_of(model), seed=1))
     model = model.to(dev).set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
-    x, cam = synth_batch(B, 256, 128, 4, seed=1234 + rank, device=dev)
+    gen = torch.Generator().manual_seed(1234 + rank)                      # SOLVER.SEED (config/defaults.py:182)
+    x = {k: torch.randn(B, 3, 256, 128, generator=gen).to(dev) for k in ("RGB", "NI", "TI")}
+    cam = torch.randint(0, 4, (B,), generator=gen).to(dev)
     # PK-structured labels: NUM_INSTANCE=4 per identity (configs/RGBNT201/DeMo.yml)
     target = (torch.arange(B, device=dev) // 4 + rank * (B // 4)) % 171
 

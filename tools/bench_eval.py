@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Evaluator timing at RGBNT100 scale (1715 queries x 8575 gallery, 5120-d features): GPU path vs the numpy oracle."""
+"""Evaluator timing at RGBNT100 scale (1715 queries x 8575 gallery, 5120-d features): GPU path vs the numpy oracle.
+The oracle is used here as the CPU baseline and checker beside the GPU path (like bench.py's cpu_baseline leg), never as the product."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

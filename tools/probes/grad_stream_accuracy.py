@@ -11,13 +11,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 from demo2_amd.modeling import make_model  # noqa: E402
 from demo2_amd.modeling.hip_backward import TrainStep  # noqa: E402
-from oracle import demo_oracle as O  # noqa: E402  (seeded weight factory only)
-from util import make_cfg, spec_of, synth_batch  # noqa: E402
+from util import make_cfg, synth_batch  # noqa: E402
 
 cfg = make_cfg("RGBNT201")
 torch.manual_seed(0)
 m = make_model(cfg, 171, 4, 0)
-m.load_state_dict(O.init_state_dict(spec_of(m), seed=1))
+with torch.no_grad():                                     # the module's own initialisation, made "alive": biases, BN statistics, token scale
+    g_ = torch.Generator().manual_seed(1)
+    for n_, p_ in m.named_parameters():
+        p_.add_(torch.randn(p_.shape, generator=g_) * (0.02 if p_.dim() > 1 else 0.05))
+    for n_, b_ in m.named_buffers():
+        if "running_var" in n_:
+            b_.mul_(1 + 0.1 * torch.rand(b_.shape, generator=g_))
+        elif "running_mean" in n_:
+            b_.add_(0.1 * torch.randn(b_.shape, generator=g_))
 m = m.to("cuda").train()
 m.geom.hdm_dropout = 0.0
 x, cam = synth_batch(8, 256, 128, 4, device="cuda")
