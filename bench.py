@@ -370,7 +370,7 @@ def main():
     if rank == 0:
         # the instrumented extra step runs on rank 0 ONLY: it must not issue collectives the other ranks never join
         saved_sync = getattr(model, "grad_sync", None)
-        model.grad_sync = None
+        model.grad_sync = False                # explicit opt-out (None would make the forward install a GradSync in a multi-rank job)
         try:
             roof = gemm_roofline(model, eager_step)
         finally:

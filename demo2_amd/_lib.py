@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdemo_hip.so")
 HEADER_PATH = os.path.join(_HERE, "..", "include", "demo_hip.h")
 
 F32, BF16 = 0, 1
+ERR_CAM_RANGE, ERR_LABEL_RANGE = 1, 2          # include/demo_hip.h: bits of the device error word
 ACT_NONE, ACT_QUICKGELU, ACT_GELU = 0, 1, 2
 
 
@@ -59,13 +60,14 @@ PROTOTYPES = {
     "demo_transpose_batched": [_P, _P, _I, _I, _I, _L, _L, _I, _P],
     "demo_colsum": [_P, _P, _I, _I, _L, _I, _I, _P],
     "demo_im2col": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "demo_embed_tokens": [_P, _I, _P, _P, _P, _P, _F, _I, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P],
+    "demo_embed_tokens": [_P, _I, _P, _P, _P, _P, _I, _F, _I, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "demo_layernorm_fwd": [_P, _P, _P, _F, _P, _I, _P, _P, _I, _I, _P],
     "demo_layernorm_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P],
     "demo_layernorm_bwd_workspace": [_I, _I],
     "demo_layernorm_bwd_lp": [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "demo_layernorm_add_fwd": [_P, _I, _P, _I, _P, _P, _P, _F, _P, _I, _P, _P, _I, _I, _P],
     "demo_adam_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _P, _P],
+    "demo_optim_step": [_I, _P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _P, _P, _P, _P],
     "demo_batchnorm_fwd": [_P, _P, _P, _P, _P, _I, _F, _F, _P, _I, _P, _P, _I, _I, _I, _I, _I, _L, _L, _P, _P],
     "demo_attention_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "demo_pife_pool_cat": [_P, _I, _P, _I, _I, _I, _P],
@@ -84,7 +86,7 @@ PROTOTYPES = {
     "demo_gemm_tn_bf16": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _F, _I, _P, _P, _L, _P],
     "demo_gemm_tn_workspace": [_I, _I, _I],
     "demo_attention_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "demo_embed_tokens_bwd": [_P, _P, _F, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P],
+    "demo_embed_tokens_bwd": [_P, _P, _I, _F, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P],
     "demo_act_bwd": [_P, _P, _I, _P, _L, _P],
     "demo_act_fwd": [_P, _I, _P, _L, _P],
     "demo_batchnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _L, _P, _P, _P],
@@ -92,8 +94,9 @@ PROTOTYPES = {
     "demo_tokens_grad": [_P, _P, _L, _P, _L, _I, _P, _I, _I, _I, _I, _P],
     "demo_hdm_vbias": [_P, _P, _L, _P, _I, _I, _I, _P],
     "demo_atmoe_gate_softmax": [_P, _P, _P, _I, _I, _I, _P],
-    "demo_xent_label_smooth": [_P, _L, _P, _I, _I, _F, _F, _P, _P, _L, _P],
+    "demo_xent_label_smooth": [_P, _L, _P, _I, _I, _F, _F, _P, _P, _L, _P, _P],
     "demo_triplet_soft_margin": [_P, _L, _P, _I, _I, _F, _P, _P, _L, _P, _P],
+    "demo_triplet_loss": [_P, _L, _P, _I, _I, _F, _F, _P, _P, _L, _P, _P],
     "demo_l2_normalize_rows": [_P, _L, _I, _I, _F, _P],
     "demo_row_sqnorm": [_P, _L, _I, _I, _P, _P],
     "demo_add_outer_sum": [_P, _L, _P, _P, _I, _I, _P],

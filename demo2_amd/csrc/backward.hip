@@ -21,9 +21,9 @@ __device__ __forceinline__ uint32_t rng_hash(uint64_t seed, uint64_t idx) {
 // ---- token embedding backward: block per token position t, threads over channels --------------------------------
 template <typename TP>
 __global__ __launch_bounds__(256) void embed_tokens_bwd_kernel(const float* __restrict__ dpre, const int64_t* __restrict__ cam,
-                                                               float cam_scale, int cam_all, TP* __restrict__ dpatch,
+                                                               int n_cam, float cam_scale, int cam_all, TP* __restrict__ dpatch,
                                                                float* __restrict__ dcls, float* __restrict__ dpos,
-                                                               float* __restrict__ dcam, int Bn, int np, int W) {
+                                                               float* __restrict__ dcam, int Bn, int np, int W, int* __restrict__ err) {
   // grid (token position, batch slab): partial sums over the slab's images, combined with fp32 atomics
   const int t = blockIdx.x, L = np + 1;
   const int per = (Bn + gridDim.y - 1) / gridDim.y;
@@ -34,7 +34,11 @@ __global__ __launch_bounds__(256) void embed_tokens_bwd_kernel(const float* __re
       const float v = dpre[((int64_t)b * L + t) * W + c];
       s += v;
       if (t > 0) io<TP>::st(dpatch + ((int64_t)b * np + (t - 1)) * W + c, v);
-      if (dcam && cam && (cam_all || t == 0)) atomicAdd(&dcam[cam[b] * (int64_t)W + c], cam_scale * v);
+      if (dcam && cam && (cam_all || t == 0)) {
+        const int64_t ci = cam[b];
+        if (ci >= 0 && ci < n_cam) atomicAdd(&dcam[ci * (int64_t)W + c], cam_scale * v);
+        else if (err && c == 0) atomicOr(err, DEMO_ERR_CAM_RANGE);       // out of range: nothing is written (demo_hip.h)
+      }
     }
     if (dpos) atomicAdd(&dpos[(int64_t)t * W + c], s);
     if (t == 0 && dcls) atomicAdd(&dcls[c], s);
@@ -430,10 +434,16 @@ __global__ __launch_bounds__(256) void tokens_grad_kernel(const float* __restric
 
 // Fused flat Adam: one pass over the flat fp32 parameter / gradient / moment buffers; also emits the bf16 weight
 // shadow for the next forward and clears the gradient (torch.optim.Adam update rule, L2 decay added to the gradient).
-__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                        float* __restrict__ v, bf16_t* __restrict__ shadow, int64_t n4, float lr,
-                                                        float b1, float b2, float eps, float wd, float bc1, float bc2_rsqrt,
-                                                        int zero_grad, const float* __restrict__ hyper) {
+// KIND: 0 torch.optim.Adam (L2 decay folded into the gradient), 1 AdamW (decoupled decay), 2 SGD with momentum b1 (v unused).
+// Parameter groups (solver/make_optimizer.py:5-17: bias decay, doubled classifier lr; plus 'no update' for parameters the reference's
+// optimizer never moves): cls[i >> 4] is the class of the 64-element block a float4 belongs to (parameters start on 64-element
+// boundaries of the flat buffer), tab[2c] its lr multiplier and tab[2c+1] its weight decay; class data absent = one group.
+template <int KIND>
+__global__ __launch_bounds__(256) void optim_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, bf16_t* __restrict__ shadow, int64_t n4, float lr,
+                                                         float b1, float b2, float eps, float wd, float bc1, float bc2_rsqrt,
+                                                         int zero_grad, const float* __restrict__ hyper,
+                                                         const uint8_t* __restrict__ cls, const float* __restrict__ tab) {
   if (hyper) {              // {lr, update count t} in device memory: a captured step replays with fresh values
     lr = hyper[0];
     const float t = hyper[1];
@@ -441,24 +451,44 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, f
     bc2_rsqrt = rsqrtf(1.f - powf(b2, t));
   }
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float lre = lr, wde = wd;
+    bool active = true;
+    if (cls) {
+      const int c = cls[i >> 4];
+      const float mult = tab[2 * c];
+      lre = lr * mult;
+      wde = tab[2 * c + 1];
+      active = mult != 0.f || wde != 0.f;      // class {0, 0}: frozen / never-used parameters keep their value and an all-zero state
+    }
     float4 pv = *reinterpret_cast<const float4*>(p + i * 4);
     const float4 gv = *reinterpret_cast<const float4*>(g + i * 4);
     float4 mv = *reinterpret_cast<const float4*>(m + i * 4);
-    float4 vv = *reinterpret_cast<const float4*>(v + i * 4);
+    float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KIND != 2) vv = *reinterpret_cast<const float4*>(v + i * 4);
     float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
     float ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+    if (active) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float gg = ga[e] + wd * pa[e];
-      ma[e] = b1 * ma[e] + (1.f - b1) * gg;
-      va[e] = b2 * va[e] + (1.f - b2) * gg * gg;
-      const float denom = sqrtf(va[e]) * bc2_rsqrt + eps;
-      pa[e] -= (lr / bc1) * (ma[e] / denom);
+      for (int e = 0; e < 4; ++e) {
+        if (KIND == 2) {                       // torch.optim.SGD: buf = momentum * buf + (g + wd p); p -= lr buf  (dampening 0)
+          const float gg = ga[e] + wde * pa[e];
+          ma[e] = b1 * ma[e] + gg;
+          pa[e] -= lre * ma[e];
+        } else {
+          float gg = ga[e];
+          if (KIND == 0) gg += wde * pa[e];
+          else pa[e] *= 1.f - lre * wde;       // AdamW: decoupled decay first
+          ma[e] = b1 * ma[e] + (1.f - b1) * gg;
+          va[e] = b2 * va[e] + (1.f - b2) * gg * gg;
+          const float denom = sqrtf(va[e]) * bc2_rsqrt + eps;
+          pa[e] -= (lre / bc1) * (ma[e] / denom);
+        }
+      }
     }
     pv = make_float4(pa[0], pa[1], pa[2], pa[3]);
     *reinterpret_cast<float4*>(p + i * 4) = pv;
     *reinterpret_cast<float4*>(m + i * 4) = make_float4(ma[0], ma[1], ma[2], ma[3]);
-    *reinterpret_cast<float4*>(v + i * 4) = make_float4(va[0], va[1], va[2], va[3]);
+    if (KIND != 2) *reinterpret_cast<float4*>(v + i * 4) = make_float4(va[0], va[1], va[2], va[3]);
     if (shadow) io<bf16_t>::st4(shadow + i * 4, pv);
     if (zero_grad) *reinterpret_cast<float4*>(g + i * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -466,30 +496,47 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, f
 
 }  // namespace
 
-extern "C" int demo_adam_step(float* p, float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1, float beta2,
-                              float eps, float weight_decay, int32_t step, int32_t zero_grad, const float* hyper_dev, void* stream) {
-  DEMO_REQUIRE(n % 4 == 0 && (step >= 1 || hyper_dev), "demo_adam_step: n must be a multiple of 4 and step >= 1");
-  const float bc1 = step >= 1 ? 1.f - powf(beta1, (float)step) : 1.f;
-  const float bc2 = step >= 1 ? 1.f - powf(beta2, (float)step) : 1.f;
+extern "C" int demo_optim_step(int32_t kind, float* p, float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int32_t step, int32_t zero_grad, const float* hyper_dev,
+                               const uint8_t* block_class, const float* class_table, void* stream) {
+  DEMO_REQUIRE(kind >= 0 && kind <= 2, "demo_optim_step: kind %d (0 Adam, 1 AdamW, 2 SGD)", kind);
+  DEMO_REQUIRE(n % 4 == 0 && (!block_class || n % 64 == 0) && (step >= 1 || hyper_dev),
+               "demo_optim_step: n must be a multiple of 4 (64 with parameter classes) and step >= 1");
+  DEMO_REQUIRE(p && g && m && (v || kind == 2), "demo_optim_step: null buffer");
+  DEMO_REQUIRE((block_class == nullptr) == (class_table == nullptr), "demo_optim_step: block_class and class_table go together");
+  const float bc1 = (step >= 1 && kind != 2) ? 1.f - powf(beta1, (float)step) : 1.f;
+  const float bc2 = (step >= 1 && kind != 2) ? 1.f - powf(beta2, (float)step) : 1.f;
   int64_t grid = cdiv64(n / 4, 256);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow_bf16, n / 4, lr,
-                     beta1, beta2, eps, weight_decay, bc1, 1.f / sqrtf(bc2), zero_grad, hyper_dev);
-  DEMO_LAUNCH_CHECK("demo_adam_step");
+  const float* hyper = kind == 2 ? nullptr : hyper_dev;     // (SGD has no bias correction; a captured SGD step is not built)
+#define DEMO_OPT(K)                                                                                                                      \
+  hipLaunchKernelGGL(optim_step_kernel<K>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow_bf16,   \
+                     n / 4, lr, beta1, beta2, eps, weight_decay, bc1, 1.f / sqrtf(bc2), zero_grad, hyper, block_class, class_table)
+  if (kind == 0) DEMO_OPT(0);
+  else if (kind == 1) DEMO_OPT(1);
+  else DEMO_OPT(2);
+#undef DEMO_OPT
+  DEMO_LAUNCH_CHECK("demo_optim_step");
   return 0;
 }
 
-extern "C" int demo_embed_tokens_bwd(const float* dpre, const int64_t* cam, float cam_scale, int32_t cam_all_tokens, void* dpatch,
-                                     int32_t dt_patch, float* dcls, float* dpos, float* dcam, int32_t Bn, int32_t np, int32_t W,
-                                     void* stream) {
+extern "C" int demo_adam_step(float* p, float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, int32_t step, int32_t zero_grad, const float* hyper_dev, void* stream) {
+  return demo_optim_step(0, p, g, m, v, shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, step, zero_grad, hyper_dev, nullptr, nullptr,
+                         stream);
+}
+
+extern "C" int demo_embed_tokens_bwd(const float* dpre, const int64_t* cam, int32_t n_cam, float cam_scale, int32_t cam_all_tokens,
+                                     void* dpatch, int32_t dt_patch, float* dcls, float* dpos, float* dcam, int32_t Bn, int32_t np,
+                                     int32_t W, int32_t* err, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const dim3 egrid(np + 1, (unsigned)(Bn >= 64 ? 16 : (Bn >= 8 ? 4 : 1)));
   if (dt_patch == DEMO_BF16)
-    hipLaunchKernelGGL(embed_tokens_bwd_kernel<bf16_t>, egrid, dim3(256), 0, s, dpre, cam, cam_scale, cam_all_tokens,
-                       (bf16_t*)dpatch, dcls, dpos, dcam, Bn, np, W);
+    hipLaunchKernelGGL(embed_tokens_bwd_kernel<bf16_t>, egrid, dim3(256), 0, s, dpre, cam, n_cam, cam_scale, cam_all_tokens,
+                       (bf16_t*)dpatch, dcls, dpos, dcam, Bn, np, W, err);
   else
-    hipLaunchKernelGGL(embed_tokens_bwd_kernel<float>, egrid, dim3(256), 0, s, dpre, cam, cam_scale, cam_all_tokens,
-                       (float*)dpatch, dcls, dpos, dcam, Bn, np, W);
+    hipLaunchKernelGGL(embed_tokens_bwd_kernel<float>, egrid, dim3(256), 0, s, dpre, cam, n_cam, cam_scale, cam_all_tokens,
+                       (float*)dpatch, dcls, dpos, dcam, Bn, np, W, err);
   DEMO_LAUNCH_CHECK("demo_embed_tokens_bwd");
   return 0;
 }

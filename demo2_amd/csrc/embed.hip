@@ -31,18 +31,26 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
 template <typename TP>
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const TP* __restrict__ patch, const float* __restrict__ cls,
                                                            const float* __restrict__ pos, const float* __restrict__ cam_embed,
-                                                           const int64_t* __restrict__ cam, float cam_scale, int cam_all,
+                                                           const int64_t* __restrict__ cam, int n_cam, float cam_scale, int cam_all,
                                                            const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                            float eps, float* __restrict__ x, float* __restrict__ pre,
                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                           int Bn, int np, int W) {
+                                                           int Bn, int np, int W, int* __restrict__ err) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int L = np + 1;
   if (row >= (int64_t)Bn * L) return;
   const int b = (int)(row / L), t = (int)(row % L);
   const int nv = W >> 2;
-  const float* ce = (cam_embed && cam) ? cam_embed + cam[b] * (int64_t)W : nullptr;
+  const float* ce = nullptr;
+  if (cam_embed && cam) {
+    int64_t ci = cam[b];
+    if (ci < 0 || ci >= n_cam) {                    // torch indexing raises here; a kernel clamps and reports (demo_hip.h)
+      if (err && t == 0 && lane == 0) atomicOr(err, DEMO_ERR_CAM_RANGE);
+      ci = ci < 0 ? 0 : n_cam - 1;
+    }
+    ce = cam_embed + ci * (int64_t)W;
+  }
   const bool add_cam = ce && (cam_all || t == 0);
   float4 v[8];
   float s = 0.f;
@@ -246,18 +254,19 @@ extern "C" int demo_im2col(const float* img, void* cols, int32_t Bn, int32_t H, 
 }
 
 extern "C" int demo_embed_tokens(const void* patch, int32_t dt_patch, const float* cls, const float* pos,
-                                 const float* cam_embed, const int64_t* cam, float cam_scale, int32_t cam_all_tokens,
+                                 const float* cam_embed, const int64_t* cam, int32_t n_cam, float cam_scale, int32_t cam_all_tokens,
                                  const float* ln_w, const float* ln_b, float eps, float* x, float* pre, float* mean,
-                                 float* rstd, int32_t Bn, int32_t np, int32_t W, void* stream) {
+                                 float* rstd, int32_t Bn, int32_t np, int32_t W, int32_t* err, void* stream) {
   DEMO_REQUIRE(W % 4 == 0 && W <= 2048, "demo_embed_tokens: W=%d unsupported", W);
+  DEMO_REQUIRE(!(cam_embed && cam) || n_cam > 0, "demo_embed_tokens: n_cam=%d with a camera table", n_cam);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)cdiv64((int64_t)Bn * (np + 1), 4));
   if (dt_patch == DEMO_BF16)
     hipLaunchKernelGGL(embed_tokens_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)patch, cls, pos, cam_embed, cam,
-                       cam_scale, cam_all_tokens, ln_w, ln_b, eps, x, pre, mean, rstd, Bn, np, W);
+                       n_cam, cam_scale, cam_all_tokens, ln_w, ln_b, eps, x, pre, mean, rstd, Bn, np, W, err);
   else
     hipLaunchKernelGGL(embed_tokens_kernel<float>, grid, dim3(256), 0, s, (const float*)patch, cls, pos, cam_embed, cam,
-                       cam_scale, cam_all_tokens, ln_w, ln_b, eps, x, pre, mean, rstd, Bn, np, W);
+                       n_cam, cam_scale, cam_all_tokens, ln_w, ln_b, eps, x, pre, mean, rstd, Bn, np, W, err);
   DEMO_LAUNCH_CHECK("demo_embed_tokens");
   return 0;
 }

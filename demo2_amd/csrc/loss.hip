@@ -27,7 +27,7 @@ __device__ __forceinline__ float block_max_256(float v, float* red) {
 // one workgroup per sample: loss += w/B * sum_k -t_k log p_k,  t = (1-eps) onehot + eps/K ;  dlogits = w/B * (p - t)
 __global__ __launch_bounds__(256) void xent_label_smooth_kernel(const float* __restrict__ logits, int64_t ld, const int64_t* __restrict__ target,
                                                                 int B, int K, float eps, float w, float* __restrict__ loss,
-                                                                float* __restrict__ dlogits, int64_t ldd) {
+                                                                float* __restrict__ dlogits, int64_t ldd, int* __restrict__ err) {
   __shared__ float red[4];
   const int b = blockIdx.x;
   const float* x = logits + (int64_t)b * ld;
@@ -42,9 +42,12 @@ __global__ __launch_bounds__(256) void xent_label_smooth_kernel(const float* __r
   s = block_sum_256(s, red);
   sx = block_sum_256(sx, red);
   const float logz = m + __logf(s);
-  const int t = (int)target[b];
-  const float wb = w / (float)B;
+  const int64_t t64 = target[b];
+  const bool bad = t64 < 0 || t64 >= K;                   // torch's scatter_ raises (softmax_loss.py:30-31); here: NaN + error bit
+  const int t = bad ? 0 : (int)t64;
+  const float wb = bad ? __builtin_nanf("") : w / (float)B;
   if (threadIdx.x == 0) {
+    if (bad && err) atomicOr(err, DEMO_ERR_LABEL_RANGE);
     const float lp_t = x[t] - logz;                       // log p of the label
     const float sum_lp = sx - (float)K * logz;            // sum_k log p_k
     atomicAdd(loss, wb * (-(1.f - eps) * lp_t - (eps / (float)K) * sum_lp));
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void xent_label_smooth_kernel(const float* __r
 //   (3) dF = Wt F by the generic GEMM.
 // (A first version computed the B^2 dot products inside this kernel, one workgroup per anchor: 458 us at D = 3584.)
 __global__ __launch_bounds__(64) void triplet_mine_kernel(const float* __restrict__ G, const int64_t* __restrict__ labels, int B, float w,
-                                                          float* __restrict__ loss, float* __restrict__ Wt) {
+                                                          float margin, float* __restrict__ loss, float* __restrict__ Wt) {
   const int i = blockIdx.x, lane = threadIdx.x;
   const int64_t li = labels[i];
   const float gii = G[(int64_t)i * B + i];
@@ -91,9 +94,11 @@ __global__ __launch_bounds__(64) void triplet_mine_kernel(const float* __restric
   if (lane != 0 || ip < 0 || in_ < 0) return;                // no positive / no negative in the batch: contributes nothing
   const float z = bp - bn;
   const float wb = w / (float)B;
-  atomicAdd(loss, wb * (z > 20.f ? z : log1pf(__expf(z))));
+  // margin < 0: SoftMarginLoss(d_an - d_ap, 1) = softplus(z); margin >= 0: MarginRankingLoss(d_an, d_ap, 1) = max(0, z + margin)
+  if (margin < 0.f) atomicAdd(loss, wb * (z > 20.f ? z : log1pf(__expf(z))));
+  else if (z + margin > 0.f) atomicAdd(loss, wb * (z + margin));
   if (!Wt) return;
-  const float g = wb / (1.f + __expf(-z));
+  const float g = margin < 0.f ? wb / (1.f + __expf(-z)) : (z + margin > 0.f ? wb : 0.f);
   // the clamp passes no gradient where it is active (dist^2 == 1e-12: coincident points, e.g. self as hardest positive)
   const int p = ip, n = in_;
   const float d2p = gii + G[(int64_t)p * B + p] - 2.f * G[(int64_t)i * B + p];
@@ -112,19 +117,26 @@ __global__ __launch_bounds__(64) void triplet_mine_kernel(const float* __restric
 }  // namespace
 
 extern "C" int demo_xent_label_smooth(const float* logits, int64_t ld, const int64_t* target, int32_t B, int32_t K, float eps, float weight,
-                                      float* loss, float* dlogits, int64_t ldd, void* stream) {
+                                      float* loss, float* dlogits, int64_t ldd, int32_t* err, void* stream) {
   DEMO_REQUIRE(logits && target && loss && B > 0 && K > 0 && ld >= K, "demo_xent_label_smooth: bad arguments");
   hipLaunchKernelGGL(xent_label_smooth_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ld, target, B, K, eps, weight, loss,
-                     dlogits, ldd);
+                     dlogits, ldd, err);
   DEMO_LAUNCH_CHECK("demo_xent_label_smooth");
   return 0;
 }
 
 extern "C" int demo_gemm(const demo_gemm_desc* d, void* stream);
 
+extern "C" int demo_triplet_loss(const float* feat, int64_t ld, const int64_t* labels, int32_t B, int32_t D, float weight, float margin,
+                                 float* loss, float* dfeat, int64_t ldd, float* workspace, void* stream);
 extern "C" int demo_triplet_soft_margin(const float* feat, int64_t ld, const int64_t* labels, int32_t B, int32_t D, float weight, float* loss,
                                         float* dfeat, int64_t ldd, float* workspace, void* stream) {
-  DEMO_REQUIRE(feat && labels && loss && workspace && B > 0 && D > 0 && ld >= D, "demo_triplet_soft_margin: bad arguments");
+  return demo_triplet_loss(feat, ld, labels, B, D, weight, -1.f, loss, dfeat, ldd, workspace, stream);
+}
+
+extern "C" int demo_triplet_loss(const float* feat, int64_t ld, const int64_t* labels, int32_t B, int32_t D, float weight, float margin,
+                                 float* loss, float* dfeat, int64_t ldd, float* workspace, void* stream) {
+  DEMO_REQUIRE(feat && labels && loss && workspace && B > 0 && D > 0 && ld >= D, "demo_triplet_loss: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   float* G = workspace;                         // (B, B) Gram matrix
   float* Wt = workspace + (size_t)B * B;        // (B, B) gradient weights
@@ -138,10 +150,10 @@ extern "C" int demo_triplet_soft_margin(const float* feat, int64_t ld, const int
   if (rc) return rc;
   if (dfeat) {
     hipError_t e = hipMemsetAsync(Wt, 0, sizeof(float) * (size_t)B * B, s);
-    if (e != hipSuccess) DEMO_FAIL(-2, "demo_triplet_soft_margin: memset failed: %s", hipGetErrorString(e));
+    if (e != hipSuccess) DEMO_FAIL(-2, "demo_triplet_loss: memset failed: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(triplet_mine_kernel, dim3(B), dim3(64), 0, s, G, labels, B, weight, loss, dfeat ? Wt : nullptr);
-  DEMO_LAUNCH_CHECK("demo_triplet_soft_margin");
+  hipLaunchKernelGGL(triplet_mine_kernel, dim3(B), dim3(64), 0, s, G, labels, B, weight, margin, loss, dfeat ? Wt : nullptr);
+  DEMO_LAUNCH_CHECK("demo_triplet_loss");
   if (dfeat) {                                  // dF[i, d] = sum_j Wt[i, j] F[j, d]
     demo_gemm_desc h = {};
     h.A = Wt; h.B = feat; h.C = dfeat;

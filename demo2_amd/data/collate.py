@@ -94,8 +94,14 @@ class DeviceFeeder:
             except StopIteration:
                 nxt = None
             if hold is not None:
-                torch.cuda.current_stream(self.device).wait_event(hold[0])
-                hold[1].record_stream(torch.cuda.current_stream(self.device))
+                consumer = torch.cuda.current_stream(self.device)
+                consumer.wait_event(hold[0])
+                hold[1].record_stream(consumer)
+                # the small tensors (labels, camera / view ids) were allocated on the side stream too: without this the caching
+                # allocator may hand their blocks to a later side-stream upload while a kernel of the consumer still reads them
+                for v in cur[1:]:
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(consumer)
             yield cur
 
     def __len__(self):

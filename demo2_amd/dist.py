@@ -41,8 +41,21 @@ class GradSync:
         self.block_ranges = list(block_ranges)
         self.tail_range = tail_range
         self.last_ranges = list(last_ranges)
-        total = sum(hi - lo for lo, hi in self.block_ranges + [self.tail_range] + self.last_ranges)
-        self.covered = total
+        ranges = sorted(self.block_ranges + [self.tail_range] + self.last_ranges)
+        for (lo, hi), (lo2, _) in zip(ranges, ranges[1:]):
+            if not (lo <= hi <= lo2):
+                raise ValueError(f"GradSync: gradient ranges overlap or are out of order: ({lo}, {hi}) then ({lo2}, ...)")
+        self.covered = sum(hi - lo for lo, hi in ranges)
+        if model is not None:
+            # the ranges are derived from the ORDER of named_parameters (embedding side, blocks 0..L-1, ln_post/proj, fusion + heads):
+            # a model whose layout breaks that order would silently leave gradients unreduced
+            n = model.ptab.flat.numel()
+            if self.covered != n or ranges[0][0] != 0 or ranges[-1][1] != n:
+                raise ValueError(f"GradSync: ranges cover {self.covered} of {n} gradient elements")
+            if any(b[0] >= b[1] for b in self.block_ranges) or any(a[1] != b[0] for a, b in zip(self.block_ranges, self.block_ranges[1:])):
+                raise ValueError("GradSync: trunk block ranges are not contiguous in layer order")
+        self.reduced_elements = 0          # elements handed to a collective since construction (tests / diagnostics)
+        self.force = False                 # issue the collectives even in a one-rank group (exercises the RCCL path on one GPU)
 
     @staticmethod
     def ranges_of(model):
@@ -63,9 +76,10 @@ class GradSync:
 
     # ------------------------------------------------------------------ collective launch
     def _reduce(self, lo: int, hi: int):
-        if hi <= lo or self.world == 1:
+        if hi <= lo or (self.world == 1 and not self.force):
             return
         view = self._flat()[lo:hi]
+        self.reduced_elements += hi - lo
         if view.is_cuda and dist.get_backend(self.group) == "nccl":
             h = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
         else:                                     # gloo has no AVG (CPU tests; GPU rehearsals of the N > 1 flow on one card)
@@ -95,10 +109,27 @@ class GradSync:
         self.handles = []
 
 
-def broadcast_parameters(model, src: int = 0, group=None):
-    """One broadcast of the flat parameter and statistics buffers at start-up (DDP's initial parameter broadcast)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+def broadcast_parameters(model, src: int = 0, group=None, force: bool = False):
+    """One broadcast of the flat parameter and statistics buffers at start-up (DDP's initial parameter broadcast).
+    force: issue the collectives in a one-rank group too (exercises the RCCL path on one GPU)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return
     dist.broadcast(model.ptab.flat, src, group=group)
     dist.broadcast(model.stab.flat, src, group=group)
     model.ptab.shadow_version = -1
+
+
+def ensure_grad_sync(model):
+    """Called by the training-mode forward.  In a multi-rank job every parameter gradient is written by kernels straight into the flat
+    buffer behind ONE autograd node, so torch's DistributedDataParallel (engine/processor.py:34-37 wraps the model with
+    find_unused_parameters=True) sees no parameter in the graph, marks all of them unused and reduces NOTHING -- silently.  The
+    reduction therefore belongs to the model: when a process group with more than one rank exists and the caller installed no GradSync,
+    one is installed here (it works with or without the DDP wrapper around the model: DDP leaves globally unused gradients alone).
+    `model.grad_sync = False` opts out explicitly (per-rank gradients wanted)."""
+    if model.grad_sync is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        model.grad_sync = GradSync(model)
+        import warnings
+        warnings.warn("demo2_amd: torch.distributed is initialised with %d ranks and no GradSync was installed; installing "
+                      "demo2_amd.dist.GradSync(model) (gradient mean over ranks inside the backward schedule).  A "
+                      "DistributedDataParallel wrapper around this model reduces nothing by itself." % dist.get_world_size())
+    return model.grad_sync if model.grad_sync else None

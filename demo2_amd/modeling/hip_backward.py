@@ -37,6 +37,8 @@ class _Boundary(torch.autograd.Function):
 
 def train_forward(m, imgs: List[torch.Tensor], cam: Optional[torch.Tensor]):
     """Training-mode forward: the reference's return tuple (engine/processor.py:80-97 pairing), differentiable."""
+    from ..dist import ensure_grad_sync
+    ensure_grad_sync(m)                    # multi-rank job without an explicit GradSync: install one (see demo2_amd/dist.py)
     m.prepare_grads()
     tape = HF.Tape()
     B = imgs[0].shape[0]
@@ -91,7 +93,7 @@ def _head_backward(m, tape, tag, dscore, dx):
 
 def model_backward(m, tape, gouts):
     _model_backward(m, tape, gouts)
-    if m.grad_sync is not None:
+    if m.grad_sync:
         m.grad_sync.backward_done()
 
 
@@ -395,7 +397,7 @@ def trunk_backward(m, tape, dtokens):
     dev = dtokens.device
     lp = T == torch.bfloat16
     act = ACT_QUICKGELU if g.arch == "clip" else ACT_GELU
-    sync = m.grad_sync
+    sync = m.grad_sync if m.grad_sync else None        # (False = explicit opt-out, see dist.ensure_grad_sync)
 
     def gw(name):
         return G[P.off(name):]
@@ -511,7 +513,8 @@ def trunk_backward(m, tape, dtokens):
     else:
         dpre = dx
     dpatch = ops.embed_tokens_bwd(dpre, t["cam3"], g.sie_coe, g.cam_all_tokens, T, gw(g.k_cls), gw(g.k_pos),
-                                  gw(g.cam_embed) if g.cam_embed else None, Bn, np_)
+                                  gw(g.cam_embed) if g.cam_embed else None, Bn, np_,
+                                  n_cam=P.index[g.cam_embed][1][0] if g.cam_embed else 0, err=m.device_errors() if g.cam_embed else None)
     ops.gemm_tn(dpatch, t["cols"], G, out_off=P.off(g.k_conv), ldc=3 * g.patch * g.patch, accumulate=True)
     if g.k_conv_bias:
         ops.colsum(dpatch, out=G[P.off(g.k_conv_bias):P.off(g.k_conv_bias) + W], accumulate=True)
@@ -519,7 +522,7 @@ def trunk_backward(m, tape, dtokens):
 
 # ------------------------------------------------------------------------------------------------ training step driver
 def label_smooth_xent(logits, target, eps=0.1):
-    """CrossEntropyLabelSmooth (layers/softmax_loss.py:23-34)."""
+    """CrossEntropyLabelSmooth (layers/softmax_loss.py:23-34); eps = 0 is F.cross_entropy."""
     logp = torch.log_softmax(logits.float(), 1)
     K = logits.shape[1]
     t = torch.full_like(logp, eps / K).scatter_(1, target[:, None], 1 - eps + eps / K)
@@ -537,12 +540,45 @@ def triplet_soft_margin(feat, labels):
     return torch.nn.functional.softplus(-(d_an - d_ap)).mean()
 
 
+def loss_settings(cfg):
+    """What layers/make_loss.py:13-80 builds from the configuration -> dict(idw, trw, eps, margin):
+      DATALOADER.SAMPLER 'softmax'         : loss = F.cross_entropy(score, target) only (:32-34; no weights, no smoothing, no triplet)
+      DATALOADER.SAMPLER 'softmax_triplet' : ID_LOSS_WEIGHT * xent + TRIPLET_LOSS_WEIGHT * triplet (:37-73) with
+          xent    = CrossEntropyLabelSmooth(eps 0.1) if MODEL.IF_LABELSMOOTH == 'on' else F.cross_entropy  (eps 0)
+          triplet = TripletLoss() soft margin if MODEL.NO_MARGIN else TripletLoss(SOLVER.MARGIN)          (:18-23)
+    margin None = soft margin.  Everything else the reference only prints a message for and then fails at the first step."""
+    sampler = cfg.DATALOADER.SAMPLER
+    if sampler == "softmax":
+        return dict(idw=1.0, trw=0.0, eps=0.0, margin=None)
+    if sampler != "softmax_triplet":
+        raise NotImplementedError(f"DATALOADER.SAMPLER={sampler!r}: make_loss builds no loss function for it (layers/make_loss.py:75-78)")
+    if cfg.MODEL.METRIC_LOSS_TYPE != "triplet":
+        raise NotImplementedError(f"MODEL.METRIC_LOSS_TYPE={cfg.MODEL.METRIC_LOSS_TYPE!r}: only 'triplet' has a loss in make_loss (:38,:71-73)")
+    return dict(idw=float(cfg.MODEL.ID_LOSS_WEIGHT), trw=float(cfg.MODEL.TRIPLET_LOSS_WEIGHT),
+                eps=0.1 if cfg.MODEL.IF_LABELSMOOTH == "on" else 0.0,
+                margin=None if cfg.MODEL.NO_MARGIN else float(cfg.SOLVER.MARGIN))
+
+
+def triplet_margin(feat, labels, margin):
+    """TripletLoss(margin): batch-hard mining + MarginRankingLoss (layers/triplet_loss.py:114-117,131-134)."""
+    feat = feat.float()
+    sq = (feat ** 2).sum(1, keepdim=True)
+    dist = (sq + sq.t() - 2 * feat @ feat.t()).clamp(min=1e-12).sqrt()
+    same = labels[:, None] == labels[None, :]
+    d_ap = torch.where(same, dist, dist.new_full((), float("-inf"))).max(1).values
+    d_an = torch.where(~same, dist, dist.new_full((), float("inf"))).min(1).values
+    return torch.clamp(d_ap - d_an + margin, min=0).mean()
+
+
 def make_loss_fn(cfg):
-    """layers/make_loss.py:37-55 ('softmax_triplet' sampler, label smoothing on, soft-margin triplet)."""
-    idw, trw = float(cfg.MODEL.ID_LOSS_WEIGHT), float(cfg.MODEL.TRIPLET_LOSS_WEIGHT)
+    """layers/make_loss.py:13-80 as a torch function (the checker of the fused loss kernels, and TrainStep(fused_loss=False))."""
+    st = loss_settings(cfg)
 
     def loss_fn(score, feat, target, target_cam=None):
-        return idw * label_smooth_xent(score, target) + trw * triplet_soft_margin(feat, target)
+        loss = st["idw"] * label_smooth_xent(score, target, st["eps"])
+        if st["trw"] != 0.0:
+            loss = loss + st["trw"] * (triplet_soft_margin(feat, target) if st["margin"] is None else triplet_margin(feat, target, st["margin"]))
+        return loss
     return loss_fn
 
 
@@ -557,19 +593,22 @@ def total_loss(outputs, target, loss_fn):
     return loss
 
 
-def fused_loss_and_grads(outputs, target, cfg):
+def fused_loss_and_grads(outputs, target, cfg, err=None):
     """The same total (pairing rule of engine/processor.py:80-97, make_loss 'softmax_triplet' with label smoothing and the
     soft-margin triplet) through the loss kernels (csrc/loss.hip): returns (loss (1,) fp32, [d loss / d output_i] for the tensor
     outputs), ready for torch.autograd.backward(outputs, grads) -- the loss itself never enters autograd."""
-    idw, trw = float(cfg.MODEL.ID_LOSS_WEIGHT), float(cfg.MODEL.TRIPLET_LOSS_WEIGHT)
+    st = loss_settings(cfg)
     n = len(outputs) - (len(outputs) % 2)
     loss = torch.zeros(1, device=outputs[0].device, dtype=torch.float32)
     roots, grads = [], []
     for i in range(0, n, 2):
         score, feat = outputs[i].detach(), outputs[i + 1].detach()
-        grads.append(ops.xent_label_smooth(score.float().contiguous(), target, loss, 0.1, idw))
-        grads.append(ops.triplet_soft_margin(feat.float().contiguous(), target, loss, trw))
-        roots += [outputs[i], outputs[i + 1]]
+        grads.append(ops.xent_label_smooth(score.float().contiguous(), target, loss, st["eps"], st["idw"], err=err))
+        roots.append(outputs[i])
+        if st["trw"] != 0.0:
+            grads.append(ops.triplet_soft_margin(feat.float().contiguous(), target, loss, st["trw"],
+                                                 margin=-1.0 if st["margin"] is None else st["margin"]))
+            roots.append(outputs[i + 1])
     if len(outputs) % 2 == 1 and torch.is_tensor(outputs[-1]):
         loss = loss + outputs[-1].detach().float().reshape(1)
         if outputs[-1].requires_grad:
@@ -580,7 +619,10 @@ def fused_loss_and_grads(outputs, target, cfg):
 
 class TrainStep:
     """One optimisation step of the reference's do_train loop (engine/processor.py:57-104) on resident tensors:
-    forward, loss, backward (with in-backward RCCL gradient reduction when world > 1), fused flat Adam.
+    forward, loss (layers/make_loss.py as configured), backward (with in-backward RCCL gradient reduction when world > 1), fused flat
+    optimizer step with the reference's parameter groups (solver/make_optimizer.py: SOLVER.OPTIMIZER_NAME Adam / AdamW / SGD,
+    WEIGHT_DECAY_BIAS, LARGE_FC_LR; frozen and never-used parameters are left alone as torch leaves them).  Configuration values
+    without an implementation raise NotImplementedError here instead of training something else silently.
 
     With graph=True (single-GPU runs) the whole step -- ~650 kernel launches, half of them tiny (fusion, heads, loss) -- is
     captured ONCE into a hipGraph and replayed: the host then issues one graph launch per step instead of driving every
@@ -598,10 +640,22 @@ class TrainStep:
         self.wd = float(cfg.SOLVER.WEIGHT_DECAY)
         self.optimizer = optimizer
         self.t = 0
+        loss_settings(cfg)                                   # raises for loss configurations make_loss has no function for
+        if "center" in str(cfg.MODEL.METRIC_LOSS_TYPE) or str(getattr(cfg.MODEL, "IF_WITH_CENTER", "no")) == "yes":
+            raise NotImplementedError("center loss (engine/processor.py:106-110) is outside the PIFE -> HDM -> ATMoE path")
+        name = str(cfg.SOLVER.OPTIMIZER_NAME)
+        kinds = {"Adam": ops.OPT_ADAM, "AdamW": ops.OPT_ADAMW, "SGD": ops.OPT_SGD}
+        if optimizer and name not in kinds:
+            raise NotImplementedError(f"SOLVER.OPTIMIZER_NAME={name!r}: the flat step implements Adam, AdamW and SGD (solver/make_optimizer.py:19-24)")
+        self.opt_kind = kinds.get(name, ops.OPT_ADAM)
+        self.momentum = float(cfg.SOLVER.MOMENTUM)
+        self.groups = None                                   # built on the model's device at the first step
         model.grad_sync = GradSync(model) if world > 1 else None
         flat = model.ptab.flat
         self.m = torch.zeros_like(flat)
         self.v = torch.zeros_like(flat)
+        if graph and self.opt_kind == ops.OPT_SGD:
+            raise NotImplementedError("graph-captured SGD steps are not built (no device-side hyper-parameters for SGD)")
         self.use_graph = bool(graph) and world == 1 and flat.is_cuda
         self._graph = None
         self._static = None
@@ -616,7 +670,7 @@ class TrainStep:
         model = self.model
         out = model(x, label=target, cam_label=cam)
         if self.fused_loss:
-            loss, roots, grads = fused_loss_and_grads(out, target, self.cfg)
+            loss, roots, grads = fused_loss_and_grads(out, target, self.cfg, err=model.device_errors())
             torch.autograd.backward(roots, grads)
             loss = loss[0]
         else:
@@ -625,9 +679,15 @@ class TrainStep:
         if self.optimizer:
             if hyper_dev is not None:
                 hyper_dev[1:2].add_(1.0)                               # the device-side update count t
-            model.adam_step(self.m, self.v, self.lr, 0.9, 0.999, 1e-8, self.wd, max(self.t, 1), hyper_dev=hyper_dev)
+            if self.groups is None or self.groups[0].device != model.ptab.flat.device:
+                s = self.cfg.SOLVER
+                self.groups = model.param_groups(self.wd, float(s.WEIGHT_DECAY_BIAS), bool(s.LARGE_FC_LR))
+            b1 = self.momentum if self.opt_kind == ops.OPT_SGD else 0.9
+            model.optim_step(self.opt_kind, self.m, self.v, self.lr, b1, 0.999, 1e-8, self.wd, max(self.t, 1), hyper_dev=hyper_dev,
+                             groups=self.groups)
         if model.seed_dev is not None:
             model.seed_dev.add_(0x9E3779B97F4A7C15 - (1 << 64))       # next dropout stream (int64 wrap-around)
+        model.device_errors().post()                                  # out-of-range labels / camera ids of this step (polled at the next forward)
         return loss
 
     def _refresh_hyper(self):

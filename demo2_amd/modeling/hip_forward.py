@@ -62,7 +62,8 @@ def trunk_forward(m, imgs: List[Tensor], cam: Optional[Tensor], T: torch.dtype, 
     cam3 = cam.repeat(3) if (cam is not None and g.cam_embed) else None
     emb = ops.embed_tokens(patch, P.f(g.k_cls).view(-1), P.f(g.k_pos).view(L, W), P.f(g.cam_embed).view(-1, W) if g.cam_embed else None,
                            cam3, g.sie_coe, g.cam_all_tokens, P.f(g.k_lnpre + ".weight") if g.k_lnpre else None,
-                           P.f(g.k_lnpre + ".bias") if g.k_lnpre else None, g.ln_eps, Bn, np_, save=tape is not None)
+                           P.f(g.k_lnpre + ".bias") if g.k_lnpre else None, g.ln_eps, Bn, np_, save=tape is not None,
+                           err=m.device_errors() if cam3 is not None else None)
     if tape is not None:
         x, pre, mean, rstd = emb
         tape.d.update(cols=cols, emb_pre=pre, emb_mean=mean, emb_rstd=rstd, cam3=cam3)

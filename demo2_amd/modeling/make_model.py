@@ -166,6 +166,7 @@ class DeMo(_Holder):
         self._plist = None
         self._anchor = None
         self._frozen = None
+        self._errors = None
         self.grad_sync = None            # set by demo2_amd.dist.GradSync for data-parallel runs
         self.overlap_dw = os.environ.get("DEMO_OVERLAP_DW", "0") == "1"   # opt-in: weight-gradient GEMMs on a side stream (hip_backward.py; measured +1.4 %)
         self._side = None
@@ -361,23 +362,61 @@ class DeMo(_Holder):
         if sentinel.grad is None or not (lo <= sentinel.grad.data_ptr() < hi):
             self.attach_grads(zero=True)
 
-    def adam_step(self, m, v, lr, beta1, beta2, eps, weight_decay, t, hyper_dev=None):
-        """Fused flat Adam over (flat params, flat grads); also refreshes the bf16 shadow and clears the gradients.
-        hyper_dev: device-resident {lr, bias corrections} (see ops.adam_step) for graph-captured steps."""
+    def unused_parameter_names(self) -> set:
+        """Parameters the constructor builds (the reference's attribute names / state-dict keys) that are NOT on this configuration's
+        forward path.  In the reference autograd leaves their .grad None, and torch optimizers skip such parameters (no update, no
+        weight decay); the flat optimizer step must do the same (tests/test_host_cpu.py checks this set against the oracle's autograd)."""
+        skip = []
+        if self.USE_DGAF:                              # DGAF-only branch (make_model.py:835-865): no PIFE reduce, no fused 'ori' head
+            skip += ["rgb_reduce.", "nir_reduce.", "tir_reduce."]
+            if self.direct:
+                skip += ["classifier.", "bottleneck."]
+        elif not self.GLOBAL_LOCAL:
+            skip += ["rgb_reduce.", "nir_reduce.", "tir_reduce."]
+        return {n for n, _ in self.named_parameters() if any(n.startswith(s) for s in skip)}
+
+    def param_groups(self, weight_decay: float, weight_decay_bias: float, large_fc_lr: bool = False):
+        """The reference's per-parameter optimizer groups (solver/make_optimizer.py:5-17) as (block_class uint8 per 64 elements of the
+        flat buffer, class_table fp32 {lr multiplier, weight decay}): "bias" in the key -> WEIGHT_DECAY_BIAS; "classifier"/"arcface" in the
+        key -> 2 x lr under LARGE_FC_LR; requires_grad False (:7-8) or never-used parameters -> class {0, 0} (left alone)."""
+        P = self.ptab
+        classes = {(0.0, 0.0): 0}
+        n_blocks = P.flat.numel() // ALIGN
+        blk = torch.zeros(n_blocks, dtype=torch.uint8)        # alignment padding: class 0 (never moves)
+        unused = self.unused_parameter_names()
+        for name, p_ in self.named_parameters():
+            if not p_.requires_grad or name in unused:
+                key = (0.0, 0.0)
+            else:
+                key = (2.0 if (large_fc_lr and ("classifier" in name or "arcface" in name)) else 1.0,
+                       float(weight_decay_bias if "bias" in name else weight_decay))
+            c = classes.setdefault(key, len(classes))
+            o, _, n = P.index[name]
+            blk[o // ALIGN:(o + n + ALIGN - 1) // ALIGN] = c
+        table = torch.tensor([v for k, _ in sorted(classes.items(), key=lambda kv: kv[1]) for v in k], dtype=torch.float32)
+        return blk.to(P.flat.device), table.to(P.flat.device)
+
+    def optim_step(self, kind, m, v, lr, beta1, beta2, eps, weight_decay, t, hyper_dev=None, groups=None):
+        """Fused flat optimizer step over (flat params, flat grads) -- kind ops.OPT_ADAM / OPT_ADAMW / OPT_SGD (beta1 = momentum) -- that
+        also refreshes the bf16 shadow and clears the gradients.  groups = param_groups(...) (None: one group, and the parameters the
+        reference's optimizer never sees are still left alone).  hyper_dev: device-resident {lr, update count} for graph-captured steps."""
         P = self.ptab
         lp = self.compute_dtype == torch.bfloat16
         if lp and P.shadow is None:
             P.shadow = torch.empty(P.flat.numel(), device=P.flat.device, dtype=torch.bfloat16)
-        # parameters the reference's optimizer never sees (requires_grad False: the BNNeck biases, make_model.py:137,177; make_optimizer.py:6-8)
-        # have no gradient, but the flat step would still apply weight decay to them: keep their values
-        frozen = [(p_, p_.detach().clone()) for p_ in self.parameters() if not p_.requires_grad] if weight_decay != 0 else []
-        ops.adam_step(P.flat, self.grad_buffer(), m, v, P.shadow if lp else None, lr, beta1, beta2, eps, weight_decay, t, zero_grad=True,
-                      hyper_dev=hyper_dev)
-        with torch.no_grad():
-            for p_, keep in frozen:
-                p_.copy_(keep)
+        if groups is None:
+            key = ("groups", float(weight_decay))
+            if key not in self._ws or self._ws[key][0].device != P.flat.device:
+                self._ws[key] = self.param_groups(weight_decay, weight_decay)
+            groups = self._ws[key]
+        ops.optim_step(kind, P.flat, self.grad_buffer(), m, v, P.shadow if lp else None, lr, beta1, beta2, eps, weight_decay, t,
+                       zero_grad=True, hyper_dev=hyper_dev, block_class=groups[0], class_table=groups[1])
         self._refresh_derived()
         P.shadow_version = (self._param_version(), bool(self.training), self.compute_dtype)
+
+    def adam_step(self, m, v, lr, beta1, beta2, eps, weight_decay, t, hyper_dev=None, groups=None):
+        """torch.optim.Adam semantics (L2 decay folded into the gradient); see optim_step."""
+        self.optim_step(ops.OPT_ADAM, m, v, lr, beta1, beta2, eps, weight_decay, t, hyper_dev=hyper_dev, groups=groups)
 
     def workspace(self, name, shape, dtype, zero=False) -> torch.Tensor:
         key = (name, tuple(shape), dtype)
@@ -386,6 +425,17 @@ class DeMo(_Holder):
             t = (torch.zeros if zero else torch.empty)(*shape, device=self.ptab.flat.device, dtype=dtype)
             self._ws[key] = t
         return t
+
+    def device_errors(self) -> ops.DeviceErrors:
+        """The model's device error word (out-of-range camera ids / labels reported by the kernels, see ops.DeviceErrors)."""
+        dev = self.ptab.flat.device
+        if self._errors is None or self._errors.word.device != dev:
+            self._errors = ops.DeviceErrors(dev)
+        return self._errors
+
+    def check_errors(self):
+        """Synchronise and raise if any kernel of this model reported an out-of-range index."""
+        self.device_errors().check()
 
     def side_stream(self):
         """Second HIP stream of the model's device (weight-gradient GEMMs run there beside the dX chain)."""
@@ -431,14 +481,22 @@ class DeMo(_Holder):
             zero_mod = {'r': (0,), 'n': (1,), 't': (2,), 'rn': (0, 1), 'rt': (0, 2), 'nt': (1, 2)}.get(self.miss_type, ())
         imgs = [t.contiguous().float() for t in (RGB, NI, TI)]
         if cam_label is not None and not torch.is_tensor(cam_label):
+            if self.geom.cam_embed and not (0 <= int(cam_label) < self.camera):      # host value: checked here, as torch indexing would raise
+                raise IndexError(f"cam_label {int(cam_label)} is out of range for {self.camera} cameras (meta_arch.py:95-99)")
             cam_label = torch.full((imgs[0].shape[0],), int(cam_label), dtype=torch.int64, device=imgs[0].device)
+        if self._errors is not None:
+            self._errors.poll()                 # an out-of-range index reported by an EARLIER call (no device sync here)
         if cam_label is not None:
             cam_label = cam_label.to(device=imgs[0].device, dtype=torch.int64)
         self.refresh_shadow()
         if self.training and torch.is_grad_enabled():
             from .hip_backward import train_forward
-            return train_forward(self, imgs, cam_label)
-        return self._forward_nograd(imgs, cam_label, zero_mod, return_pattern)
+            out = train_forward(self, imgs, cam_label)
+        else:
+            out = self._forward_nograd(imgs, cam_label, zero_mod, return_pattern)
+        if self._errors is not None:
+            self._errors.post()                 # read back behind this call's kernels, looked at by the next call's poll()
+        return out
 
     def _forward_nograd(self, imgs, cam, zero_mod, return_pattern, training=None):
         training = self.training if training is None else training

@@ -38,6 +38,48 @@ def _req_cuda(*ts):
             raise _lib.DemoHipError("demo2_amd ops need HIP device tensors (no CPU fallback)")
 
 
+class DeviceErrors:
+    """Caller-owned device error word of the C ABI (include/demo_hip.h, DEMO_ERR_*): kernels that take an index argument (camera
+    ids, class labels) cannot raise the way torch's indexing does in the reference, so they clamp / poison the offending sample and OR a
+    bit into this word.  It is read back WITHOUT a device synchronisation: `post()` queues an async copy into pinned host memory
+    behind the kernels issued so far, `poll()` (called at the start of the next forward) raises once that copy has completed and
+    shows a bit; `check()` synchronises and raises (tests, end of an evaluation, before a checkpoint is written)."""
+    MESSAGES = {_lib.ERR_CAM_RANGE: "cam_label outside [0, camera_num) (the reference's cv_embed[cam_label] raises IndexError)",
+                _lib.ERR_LABEL_RANGE: "class label outside [0, num_classes) (the reference's label-smoothing scatter_ raises)"}
+
+    def __init__(self, device):
+        self.word = torch.zeros(1, device=device, dtype=torch.int32)
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory() if self.word.is_cuda else None
+        self.event = None
+
+    def ptr(self):
+        return self.word.data_ptr()
+
+    def post(self):
+        if self.host is None or torch.cuda.is_current_stream_capturing():
+            return
+        self.host.copy_(self.word, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def _raise_if(self, bits: int):
+        if bits:
+            self.word.zero_()
+            if self.host is not None:
+                self.host.zero_()
+            self.event = None
+            what = "; ".join(m for b, m in self.MESSAGES.items() if bits & b) or f"error bits {bits:#x}"
+            raise IndexError("demo2_amd kernel reported an out-of-range index in an earlier launch: " + what)
+
+    def poll(self):
+        if self.event is not None and self.event.query():
+            self.event = None
+            self._raise_if(int(self.host[0]))
+
+    def check(self):
+        self._raise_if(int(self.word.item()))
+
+
 # ------------------------------------------------------------------------------------------------
 # GEMM
 # ------------------------------------------------------------------------------------------------
@@ -219,8 +261,9 @@ def im2col_into(img: Tensor, cols: Tensor, patch: int, stride: int) -> Tensor:
 
 def embed_tokens(patch_out: Tensor, cls: Tensor, pos: Tensor, cam_embed: Optional[Tensor], cam: Optional[Tensor],
                  cam_scale: float, cam_all_tokens: bool, ln_w: Optional[Tensor], ln_b: Optional[Tensor], eps: float,
-                 Bn: int, n_patch: int, save: bool = False):
-    """-> x (Bn*(n_patch+1), W) fp32 [, pre, mean, rstd when save]"""
+                 Bn: int, n_patch: int, save: bool = False, err: Optional[DeviceErrors] = None):
+    """-> x (Bn*(n_patch+1), W) fp32 [, pre, mean, rstd when save].  cam_embed (n_cam, W); camera ids outside the table are clamped and
+    reported through `err` (DeviceErrors)."""
     _req_cuda(patch_out, cls, pos)
     W = patch_out.shape[1]
     rows = Bn * (n_patch + 1)
@@ -234,8 +277,9 @@ def embed_tokens(patch_out: Tensor, cls: Tensor, pos: Tensor, cam_embed: Optiona
     if cam is not None:
         assert cam.dtype == torch.int64 and cam.numel() == Bn
     check(_lib.load().demo_embed_tokens(patch_out.data_ptr(), dt_code(patch_out.dtype), cls.data_ptr(), pos.data_ptr(),
-                                        _ptr(cam_embed), _ptr(cam), float(cam_scale), int(cam_all_tokens), _ptr(ln_w), _ptr(ln_b),
-                                        float(eps), x.data_ptr(), _ptr(pre), _ptr(mean), _ptr(rstd), Bn, n_patch, W, _stream()),
+                                        _ptr(cam_embed), _ptr(cam), 0 if cam_embed is None else cam_embed.shape[0], float(cam_scale),
+                                        int(cam_all_tokens), _ptr(ln_w), _ptr(ln_b), float(eps), x.data_ptr(), _ptr(pre), _ptr(mean),
+                                        _ptr(rstd), Bn, n_patch, W, None if err is None else err.ptr(), _stream()),
           "demo_embed_tokens")
     return (x, pre, mean, rstd) if save else x
 
@@ -341,6 +385,25 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, shadow: Optional[Tenso
     check(_lib.load().demo_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(shadow), n, float(lr), float(beta1),
                                      float(beta2), float(eps), float(weight_decay), int(step), int(zero_grad), _ptr(hyper_dev), _stream()),
           "demo_adam_step")
+
+
+OPT_ADAM, OPT_ADAMW, OPT_SGD = 0, 1, 2
+
+
+def optim_step(kind: int, p: Tensor, g: Tensor, m: Tensor, v: Optional[Tensor], shadow: Optional[Tensor], lr: float, beta1: float, beta2: float,
+               eps: float, weight_decay: float, step: int, zero_grad: bool = True, hyper_dev: Optional[Tensor] = None,
+               block_class: Optional[Tensor] = None, class_table: Optional[Tensor] = None):
+    """Flat optimizer step in general form (demo_optim_step): kind OPT_ADAM / OPT_ADAMW / OPT_SGD (beta1 = momentum); block_class
+    (uint8 per 64 elements) + class_table (fp32 {lr multiplier, weight decay} per class) are the reference's parameter groups."""
+    _req_cuda(p, g, m, v, block_class, class_table)
+    n = p.numel()
+    assert g.numel() == n and m.numel() == n and (v is None or v.numel() == n) and (shadow is None or shadow.numel() == n)
+    if block_class is not None:
+        assert block_class.dtype == torch.uint8 and block_class.numel() * 64 == n and class_table.dtype == torch.float32
+        assert class_table.numel() % 2 == 0 and block_class.is_contiguous() and class_table.is_contiguous()
+    check(_lib.load().demo_optim_step(int(kind), p.data_ptr(), g.data_ptr(), m.data_ptr(), _ptr(v), _ptr(shadow), n, float(lr), float(beta1),
+                                      float(beta2), float(eps), float(weight_decay), int(step), int(zero_grad), _ptr(hyper_dev),
+                                      _ptr(block_class), _ptr(class_table), _stream()), "demo_optim_step")
 
 
 def batchnorm_fwd(x: Tensor, w: Tensor, b: Tensor, running_mean: Tensor, running_var: Tensor, training: bool, momentum: float,
@@ -575,13 +638,17 @@ def attention_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, Bn: int, 
 
 
 def embed_tokens_bwd(dpre: Tensor, cam: Optional[Tensor], cam_scale: float, cam_all_tokens: bool, dpatch_dtype: torch.dtype,
-                     dcls: Tensor, dpos: Tensor, dcam: Optional[Tensor], Bn: int, n_patch: int) -> Tensor:
-    """dcls / dpos / dcam are accumulated into (fp32 views of the flat gradient buffer); returns dpatch (Bn*n_patch, W)."""
+                     dcls: Tensor, dpos: Tensor, dcam: Optional[Tensor], Bn: int, n_patch: int, n_cam: int = 0,
+                     err: Optional[DeviceErrors] = None) -> Tensor:
+    """dcls / dpos / dcam are accumulated into (fp32 views of the flat gradient buffer; dcam has n_cam rows); returns dpatch (Bn*n_patch, W)."""
+    if dcam is not None and cam is not None and n_cam <= 0:
+        raise ValueError("embed_tokens_bwd: n_cam (rows of the camera table) is required with dcam")
     _req_cuda(dpre, dcls, dpos)
     W = dpre.shape[1]
     dpatch = torch.empty(Bn * n_patch, W, device=dpre.device, dtype=dpatch_dtype)
-    check(_lib.load().demo_embed_tokens_bwd(dpre.data_ptr(), _ptr(cam), float(cam_scale), int(cam_all_tokens), dpatch.data_ptr(),
-                                            dt_code(dpatch_dtype), dcls.data_ptr(), dpos.data_ptr(), _ptr(dcam), Bn, n_patch, W, _stream()),
+    check(_lib.load().demo_embed_tokens_bwd(dpre.data_ptr(), _ptr(cam), int(n_cam), float(cam_scale), int(cam_all_tokens), dpatch.data_ptr(),
+                                            dt_code(dpatch_dtype), dcls.data_ptr(), dpos.data_ptr(), _ptr(dcam), Bn, n_patch, W,
+                                            None if err is None else err.ptr(), _stream()),
           "demo_embed_tokens_bwd")
     return dpatch
 
@@ -653,27 +720,30 @@ def atmoe_gate_softmax(q: Tensor, k: Tensor, Bs: int, Cd: int, H: int) -> Tensor
 # ------------------------------------------------------------------------------------------------
 # training losses (value + gradient in one launch)
 # ------------------------------------------------------------------------------------------------
-def xent_label_smooth(logits: Tensor, target: Tensor, loss: Tensor, eps: float = 0.1, weight: float = 1.0, need_grad: bool = True):
-    """loss[0] += weight * CrossEntropyLabelSmooth(logits, target); returns weight * d/dlogits (or None)."""
+def xent_label_smooth(logits: Tensor, target: Tensor, loss: Tensor, eps: float = 0.1, weight: float = 1.0, need_grad: bool = True,
+                      err: Optional[DeviceErrors] = None):
+    """loss[0] += weight * CrossEntropyLabelSmooth(logits, target); returns weight * d/dlogits (or None).  A label outside [0, K) poisons
+    that sample with NaN and is reported through `err`."""
     _req_cuda(logits, target, loss)
     assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1 and target.dtype == torch.int64
     assert loss.dtype == torch.float32 and loss.numel() >= 1
     B, K = logits.shape
     d = torch.empty(B, K, device=logits.device, dtype=torch.float32) if need_grad else None
     check(_lib.load().demo_xent_label_smooth(logits.data_ptr(), logits.stride(0), target.data_ptr(), B, K, float(eps), float(weight),
-                                             loss.data_ptr(), _ptr(d), K, _stream()), "demo_xent_label_smooth")
+                                             loss.data_ptr(), _ptr(d), K, None if err is None else err.ptr(), _stream()), "demo_xent_label_smooth")
     return d
 
 
-def triplet_soft_margin(feat: Tensor, labels: Tensor, loss: Tensor, weight: float = 1.0, need_grad: bool = True):
-    """loss[0] += weight * TripletLoss()(feat, labels) (batch-hard, soft margin); returns weight * d/dfeat (or None)."""
+def triplet_soft_margin(feat: Tensor, labels: Tensor, loss: Tensor, weight: float = 1.0, need_grad: bool = True, margin: float = -1.0):
+    """loss[0] += weight * TripletLoss(margin)(feat, labels) (batch-hard; margin < 0 = the soft-margin form, MODEL.NO_MARGIN True);
+    returns weight * d/dfeat (or None)."""
     _req_cuda(feat, labels, loss)
     assert feat.dtype == torch.float32 and feat.dim() == 2 and feat.stride(1) == 1 and labels.dtype == torch.int64
     B, D = feat.shape
     d = torch.empty(B, D, device=feat.device, dtype=torch.float32) if need_grad else None
     ws = torch.empty(2 * B * B, device=feat.device, dtype=torch.float32)        # Gram matrix + gradient weights
-    check(_lib.load().demo_triplet_soft_margin(feat.data_ptr(), feat.stride(0), labels.data_ptr(), B, D, float(weight), loss.data_ptr(),
-                                               _ptr(d), D, ws.data_ptr(), _stream()), "demo_triplet_soft_margin")
+    check(_lib.load().demo_triplet_loss(feat.data_ptr(), feat.stride(0), labels.data_ptr(), B, D, float(weight), float(margin), loss.data_ptr(),
+                                        _ptr(d), D, ws.data_ptr(), _stream()), "demo_triplet_loss")
     return d
 
 

@@ -96,6 +96,11 @@ int demo_transpose_batched(const void* src, void* dst, int32_t rows, int32_t col
 /* column sums: out[n] (+)= sum_m X[m, n]   (bias gradients) */
 int demo_colsum(const void* X, float* out, int32_t M, int32_t N, int64_t ldx, int32_t dt, int32_t accumulate, void* stream);
 
+/* ---- device-side argument errors ------------------------------------------------------------ */
+/* Bits a kernel ORs into the caller's device error word (int32) when an index argument is out of range; see the entries that take
+ * `err`.  The word is caller-owned (the library keeps no device state); demo2_amd polls it without a device sync (ops.DeviceErrors). */
+enum { DEMO_ERR_CAM_RANGE = 1, DEMO_ERR_LABEL_RANGE = 2 };
+
 /* ---- patch embedding ---------------------------------------------------------------------- */
 /* im2col for the patch-embed conv (clip/model.py:432,447-449; vit_pytorch.py:303,321-323):
  * img fp32 (Bn,3,H,W) -> cols T (Bn*ny*nx, 3*p*p), column order (c,ky,kx) = conv weight order. */
@@ -107,11 +112,14 @@ int demo_im2col(const float* img, void* cols, int32_t Bn, int32_t H, int32_t W, 
  * x[b,0,:] = cls + pos[0] + cam_scale*cam_embed[cam[b]] ; x[b,1+i,:] = patch[b,i,:] + pos[1+i]
  *            (+ cam_scale*cam_embed[cam[b]] on every token when cam_all_tokens, the ViT SIE rule);
  * if ln_w != NULL: x = LayerNorm(x; ln_w, ln_b, eps).  x is the fp32 residual stream (Bn*(1+np), W).
- * pre (optional, fp32) receives the un-normalised sum for the backward pass. */
+ * pre (optional, fp32) receives the un-normalised sum for the backward pass.
+ * n_cam = rows of cam_embed.  The reference's torch indexing raises for cam[b] outside [0, n_cam) (meta_arch.py:95-99); a kernel
+ * cannot raise, so such an index is clamped into the table (no out-of-bounds read of the neighbouring parameters of the flat
+ * buffer) and bit DEMO_ERR_CAM_RANGE is OR-ed into *err (device int32, optional): the host raises at its next poll of the word. */
 int demo_embed_tokens(const void* patch, int32_t dt_patch, const float* cls, const float* pos,
-                      const float* cam_embed, const int64_t* cam, float cam_scale, int32_t cam_all_tokens,
+                      const float* cam_embed, const int64_t* cam, int32_t n_cam, float cam_scale, int32_t cam_all_tokens,
                       const float* ln_w, const float* ln_b, float eps, float* x, float* pre, float* mean, float* rstd,
-                      int32_t Bn, int32_t np, int32_t W, void* stream);
+                      int32_t Bn, int32_t np, int32_t W, int32_t* err, void* stream);
 
 /* ---- normalisation ------------------------------------------------------------------------ */
 /* LayerNorm over the last dim of fp32 x (M, D) -> y (dtype dtY); optional mean/rstd (M) saved for backward.
@@ -239,9 +247,11 @@ int64_t demo_gemm_tn_workspace(int32_t Mo, int32_t No, int32_t Kr);
 int demo_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int32_t Bn,
                        int32_t L, int32_t H, int32_t dh, int32_t dt, void* stream);
 /* Adjoint of demo_embed_tokens w.r.t. its un-normalised sum `pre` (dpre fp32 (Bn*(1+np), W)):
- * dpatch (dtype dt_patch) = rows 1.., dcls += sum_b row 0, dpos[t] += sum_b row t, dcam[cam[b]] += cam_scale * rows. */
-int demo_embed_tokens_bwd(const float* dpre, const int64_t* cam, float cam_scale, int32_t cam_all_tokens, void* dpatch,
-                          int32_t dt_patch, float* dcls, float* dpos, float* dcam, int32_t Bn, int32_t np, int32_t W, void* stream);
+ * dpatch (dtype dt_patch) = rows 1.., dcls += sum_b row 0, dpos[t] += sum_b row t, dcam[cam[b]] += cam_scale * rows.
+ * cam[b] outside [0, n_cam) contributes nothing to dcam (and sets DEMO_ERR_CAM_RANGE in *err, as in the forward). */
+int demo_embed_tokens_bwd(const float* dpre, const int64_t* cam, int32_t n_cam, float cam_scale, int32_t cam_all_tokens, void* dpatch,
+                          int32_t dt_patch, float* dcls, float* dpos, float* dcam, int32_t Bn, int32_t np, int32_t W, int32_t* err,
+                          void* stream);
 /* y = act(pre), fp32, n elements (used where the product itself ran split-K and could not apply the activation) */
 int demo_act_fwd(const float* pre, int32_t kind, float* y, int64_t n, void* stream);
 /* dx = dy * act'(pre), fp32, n elements */
@@ -258,6 +268,14 @@ int demo_batchnorm_bwd(const float* dy, const float* x, const float* w, const fl
  * launch arguments of a replay are frozen, so the count is advanced by a captured device op and lr by a stream-ordered fill. */
 int demo_adam_step(float* p, float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int32_t step, int32_t zero_grad, const float* hyper_dev, void* stream);
+/* The flat optimizer step in general form (solver/make_optimizer.py:4-28): kind 0 = torch.optim.Adam, 1 = AdamW (decoupled decay),
+ * 2 = SGD with momentum beta1 (v may be NULL; bias corrections unused).  Parameter groups: block_class (optional, uint8 per 64-element
+ * block of the flat buffer -- every parameter starts on such a boundary) indexes class_table (device floats {lr multiplier, weight
+ * decay} per class): WEIGHT_DECAY_BIAS for "bias" keys, 2 x lr for classifiers under LARGE_FC_LR, and {0, 0} for parameters the
+ * reference's optimizer never moves (requires_grad False, or no gradient in this configuration: torch skips grad-None parameters). */
+int demo_optim_step(int32_t kind, float* p, float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int32_t step, int32_t zero_grad, const float* hyper_dev, const uint8_t* block_class,
+                    const float* class_table, void* stream);
 /* out[b, 0:C] += dtokens[b, 0, :]   (row-0 gradient of a token stream -> gradient of the global feature) */
 int demo_token0_grad(const float* dtokens, float* out, int64_t out_ld, int32_t Bn, int32_t L, int32_t C, void* stream);
 /* final trunk-output gradient (dtype dt): row 0 = dcls[b] (+ dtok row 0 if keep_row0); row l>=1 = dtok[b,l] + dmean[b]/(L-1);
@@ -268,9 +286,11 @@ int demo_tokens_grad(const float* dtok, const float* dcls, int64_t cls_ld, const
 /* ---- training losses: value and gradient in one launch -----------------------------------------
  * CrossEntropyLabelSmooth (layers/softmax_loss.py:23-34): *loss += weight * mean_b sum_k -t_bk log softmax(logits_b)_k with
  * t = (1-eps) onehot(target) + eps/K;  dlogits (optional, (B, ldd)) = weight * d/dlogits.  loss is a device scalar the
- * caller zeroes once per step. */
+ * caller zeroes once per step.  target[b] outside [0, K) (torch's scatter_ raises there, softmax_loss.py:30-31): the sample
+ * contributes a NaN to *loss, its dlogits row is NaN, nothing out of bounds is read, and DEMO_ERR_LABEL_RANGE is OR-ed into *err
+ * (device int32, optional). */
 int demo_xent_label_smooth(const float* logits, int64_t ld, const int64_t* target, int32_t B, int32_t K, float eps, float weight,
-                           float* loss, float* dlogits, int64_t ldd, void* stream);
+                           float* loss, float* dlogits, int64_t ldd, int32_t* err, void* stream);
 /* TripletLoss() without margin (layers/triplet_loss.py:16-31,51-104,121-135): euclidean distances as the reference forms them
  * (sqrt(clamp(|a|^2+|b|^2-2ab, 1e-12))), batch-hard mining (hardest positive incl. self, hardest negative), SoftMarginLoss:
  * *loss += weight * mean_i softplus(d_ap - d_an);  dfeat (optional, (B, ldd), OVERWRITTEN) = weight * d/dfeat.
@@ -278,6 +298,10 @@ int demo_xent_label_smooth(const float* logits, int64_t ld, const int64_t* targe
  * demo_gemm's fp32 kernel). */
 int demo_triplet_soft_margin(const float* feat, int64_t ld, const int64_t* labels, int32_t B, int32_t D, float weight, float* loss,
                              float* dfeat, int64_t ldd, float* workspace, void* stream);
+/* The same with the reference's other triplet form (layers/triplet_loss.py:114-117,131-134; MODEL.NO_MARGIN False): margin >= 0 selects
+ * MarginRankingLoss(d_an, d_ap, 1) = mean_i max(0, d_ap - d_an + margin); margin < 0 is the soft-margin form above. */
+int demo_triplet_loss(const float* feat, int64_t ld, const int64_t* labels, int32_t B, int32_t D, float weight, float margin, float* loss,
+                      float* dfeat, int64_t ldd, float* workspace, void* stream);
 
 /* ---- retrieval evaluator (utils/metrics.py) ---------------------------------------------------------
  * R1_mAP_eval.compute (:341-369): F.normalize -> euclidean_distance (:395-401) -> eval_func (:110-169); R1_mAP (:172-218) with

@@ -34,7 +34,7 @@ def _model_and_batch(rank_seed):
     return cfg, m, x, cam, target
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, explicit=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -45,20 +45,31 @@ def _worker(rank, world, port, q):
         from demo2_amd.modeling.hip_backward import TrainStep
         cfg, m, x, cam, target = _model_and_batch(rank)
         broadcast_parameters(m)
-        ts = TrainStep(m, cfg, world, optimizer=False)               # installs GradSync (world > 1)
-        assert m.grad_sync is not None
-        loss = ts.step(x, target, cam)
+        if explicit:
+            ts = TrainStep(m, cfg, world, optimizer=False)           # installs GradSync (world > 1)
+            assert m.grad_sync is not None
+        else:
+            # what a caller that only knows the reference's loop does: nothing (or a DistributedDataParallel wrapper, which sees no
+            # parameter in the autograd graph and reduces nothing).  The training-mode forward must install the reduction itself.
+            ts = TrainStep(m, cfg, 1, optimizer=False)
+            assert m.grad_sync is None
+        import warnings
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            loss = ts.step(x, target, cam)
+        assert m.grad_sync is not None and (explicit or any("GradSync" in str(i.message) for i in w))
         torch.cuda.synchronize()
         q.put((rank, m.grad_buffer().detach().cpu().numpy(), float(loss)))     # by value: the worker exits right after
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_gradient_mean_through_the_backward_schedule():
+@pytest.mark.parametrize("explicit", [True, False])
+def test_two_rank_gradient_mean_through_the_backward_schedule(explicit):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, explicit)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])

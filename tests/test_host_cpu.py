@@ -179,3 +179,78 @@ def test_checkpoint_round_trip_through_load_param(tmp_path):
     assert int(b.bottleneck.num_batches_tracked) == 7
     for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
         assert ka == kb and torch.equal(va, vb)
+
+
+# ---- round-2 advisor items (host side) -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kw", [dict(), dict(direct=0), dict(GLOBAL_LOCAL=False), dict(HDM=False, ATM=False, USE_DGAF=True),
+                                dict(HDM=False, ATM=False, USE_DGAF=True, direct=0), dict(HDM=True, ATM=False)])
+def test_unused_parameters_are_the_ones_autograd_leaves_without_gradient(kw):
+    """torch optimizers skip parameters whose .grad is None; the flat optimizer step must leave exactly those alone.  The set the model
+    declares (DeMo.unused_parameter_names) is checked against autograd of the CPU oracle on the same configuration."""
+    kw = dict(kw)
+    direct = kw.pop("direct", 1)
+    m = make_model(small_cfg("clip", head=4, direct=direct, **kw), 11, 3, 0)
+    spec = spec_of(m)
+    spec.hdm_dropout = 0.0
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in O.init_state_dict(spec, seed=1).items()}
+    from util import synth_batch
+    x, cam = synth_batch(4, 64, 32, 3)
+    out = O.model_forward(sd, spec, x, cam, training=True, updates={})
+    O.train_loss(out, torch.tensor([0, 0, 1, 1]), 0.25, 1.0).backward()
+    names = {n for n, _ in m.named_parameters()}
+    no_grad = {k for k, v in sd.items() if k in names and v.requires_grad and v.grad is None}
+    assert m.unused_parameter_names() == no_grad, (sorted(m.unused_parameter_names() ^ no_grad))
+
+
+def test_param_groups_follow_make_optimizer():
+    """solver/make_optimizer.py:5-17: 'bias' keys take WEIGHT_DECAY_BIAS, classifiers 2 x lr under LARGE_FC_LR, requires_grad False is
+    skipped; never-used parameters (grad None in torch) are left alone too."""
+    m = make_model(small_cfg("clip", head=4, direct=1, HDM=False, ATM=False, USE_DGAF=True), 11, 3, 0)
+    blk, tab = m.param_groups(1e-4, 5e-5, large_fc_lr=True)
+    tab = tab.view(-1, 2)
+    assert tab[0].tolist() == [0.0, 0.0] and blk.numel() * 64 == m.ptab.flat.numel()
+
+    def cls_of(name):
+        o, _, n = m.ptab.index[name]
+        c = blk[o // 64:(o + n + 63) // 64]
+        assert (c == c[0]).all()
+        return tuple(round(v, 7) for v in tab[int(c[0])].tolist())
+    assert cls_of("BACKBONE.base.transformer.resblocks.0.attn.in_proj_weight") == (1.0, 1e-4)
+    assert cls_of("BACKBONE.base.transformer.resblocks.0.attn.in_proj_bias") == (1.0, 5e-5)
+    assert cls_of("classifier_dgaf.weight") == (2.0, 1e-4)
+    assert cls_of("bottleneck_dgaf.bias") == (0.0, 0.0)            # requires_grad False (make_model.py:137,177)
+    assert cls_of("rgb_reduce.1.weight") == (0.0, 0.0)             # not on the DGAF branch's path: torch never moves it
+    assert cls_of("classifier.weight") == (0.0, 0.0)
+
+
+def test_train_step_rejects_configurations_it_does_not_implement():
+    from demo2_amd.modeling.hip_backward import TrainStep, loss_settings
+    base = small_cfg("clip")
+    m = make_model(base, 11, 3, 0)
+    for path, val in ((("SOLVER", "OPTIMIZER_NAME"), "RMSprop"), (("DATALOADER", "SAMPLER"), "triplet"),
+                      (("MODEL", "METRIC_LOSS_TYPE"), "triplet_center"), (("MODEL", "IF_WITH_CENTER"), "yes")):
+        c = base.clone()
+        c[path[0]][path[1]] = val
+        with pytest.raises(NotImplementedError):
+            TrainStep(m, c, 1)
+    for name in ("Adam", "AdamW", "SGD"):
+        c = base.clone()
+        c.SOLVER.OPTIMIZER_NAME = name
+        TrainStep(m, c, 1)
+    c = base.clone()
+    c.MODEL.NO_MARGIN, c.MODEL.IF_LABELSMOOTH = False, "off"
+    assert loss_settings(c) == dict(idw=0.25, trw=1.0, eps=0.0, margin=0.3)
+    c.DATALOADER.SAMPLER = "softmax"
+    assert loss_settings(c) == dict(idw=1.0, trw=0.0, eps=0.0, margin=None)
+
+
+def test_gradsync_rejects_ranges_that_do_not_tile_the_buffer():
+    from demo2_amd.dist import GradSync
+    g = torch.zeros(1000)
+    with pytest.raises(ValueError):
+        GradSync(flat_grad=g, block_ranges=[(100, 500), (400, 700)], tail_range=(700, 1000), last_ranges=[(0, 100)])      # overlap
+    m = make_model(small_cfg(), 11, 3, 0)
+    s = GradSync(m)
+    assert s.covered == m.ptab.flat.numel()
+    with pytest.raises(ValueError):
+        GradSync(flat_grad=g, block_ranges=[(500, 100)], tail_range=(700, 1000), last_ranges=[])                          # hi < lo
