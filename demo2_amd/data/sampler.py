@@ -83,10 +83,11 @@ class RandomIdentitySampler(Sampler):
         return self.length
 
 
-def _shared_seed(seed: Optional[int] = None) -> int:
-    """One seed for all ranks (sampler_ddp.py:103-114): rank 0's draw, broadcast as a single int64."""
+def _shared_seed(seed: Optional[int] = None, force: bool = False) -> int:
+    """One seed for all ranks (sampler_ddp.py:103-114): rank 0's draw, broadcast as a single int64.
+    force: broadcast in a one-rank group too (exercises the RCCL path on one GPU)."""
     s = int(np.random.SeedSequence().generate_state(1)[0]) if seed is None else int(seed)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
         t = torch.tensor([s], dtype=torch.int64, device=dev)
         dist.broadcast(t, 0)
