@@ -44,6 +44,10 @@ def parse():
                          "measurement, not BASELINE.json's metric)")
     ap.add_argument("--eager-baseline", action="store_true",
                     help="also time the torch restatement of the path with PyTorch-ROCm eager on this GPU (bf16 autocast); baseline only")
+    ap.add_argument("--config", choices=["RGBNT201", "RGBNT100", "vit"], default="RGBNT201",
+                    help="RGBNT201: the headline workload (configs/RGBNT201/DeMo.yml, CLIP ViT-B/16, 256x128, HEAD 4, DIRECT 1).  Side lines, NOT "
+                         "BASELINE.json's metric: RGBNT100 = configs/RGBNT100/DeMo.yml (128x256, HEAD 8, DIRECT 0, 50 classes, 8 cameras; "
+                         "BASELINE configs[4]); vit = the ImageNet ViT-B/16 trunk (C = 768, HEAD 12; SURVEY 8 config V)")
     ap.add_argument("--host-input", action="store_true",
                     help="train mode: copy each batch from pinned host memory (double-buffered side stream); PCIe-inclusive rate")
     return ap.parse_args()
@@ -146,15 +150,25 @@ def gemm_roofline(model, step_fn):
     dom = max(stats, key=lambda k: stats[k]["ms_per_step"])
     s = stats[dom]
     # HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE doubled for gfx950 + WRITE_SIZE, collected
-    # with rocprofv3 in separate runs of this same command and committed under profiles/): not measurable in-process
+    # with rocprofv3 in separate runs of this same command and committed under profiles/): not measurable in-process.  The newest
+    # profiles/rNN_hbm_traffic_pmc.json is used; `stale` says the kernel sources have changed since it was taken.
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")) as f:
-            t = json.load(f)["kernels"].get(s["kernel"])
+        import glob
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from pmc_traffic import csrc_sha16
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.json")))[-1]
+        with open(path) as f:
+            doc = json.load(f)
+        t = doc["kernels"].get(s["kernel"])
         if t and B_TRAFFIC_VALID[0]:
             traffic = {"hbm_mb_per_launch": t["hbm_mb_per_launch"], "algorithmic_mb_per_launch": s["algorithmic_mb_per_launch"],
-                       "source": "profiles/r01_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, B=128 train step)"}
-    except (OSError, ValueError, KeyError):
+                       "stale": doc.get("csrc_sha16") != csrc_sha16(),
+                       "source": "profiles/" + os.path.basename(path) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, B=128 train step)"}
+            for extra in ("fetch_served_by", "note_l2"):
+                if extra in t:
+                    traffic[extra] = t[extra]
+    except (OSError, ValueError, KeyError, IndexError, ImportError):
         pass
     out = {"bound": "mfma", "kernel": s["kernel"], "achieved": s["achieved_tflops"], "peak": MFMA_BF16_PEAK_TFLOPS,
            "unit": "TFLOP/s", "frac": round(s["achieved_tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
@@ -167,7 +181,7 @@ def gemm_roofline(model, step_fn):
     return out
 
 
-def cpu_baseline(mode, seconds, fusion="atmoe"):
+def cpu_baseline(mode, seconds, fusion="atmoe", config="RGBNT201"):
     """The CPU restatement (oracle) on this host's cores, bounded sample of the same workload (B=2 batches)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import demo_oracle as O
@@ -175,8 +189,14 @@ def cpu_baseline(mode, seconds, fusion="atmoe"):
     # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     spec = O.Spec() if fusion == "atmoe" else O.Spec(hdm=False, atm=False, use_dgaf=True)
+    h, w, cams = 256, 128, 4
+    if config == "RGBNT100":
+        spec = O.Spec(img_h=128, img_w=256, moe_head=8, direct=0, num_classes=50, camera_num=8)
+        h, w, cams = 128, 256, 8
+    elif config == "vit":
+        spec = O.Spec(arch="vit", width=768, feat_dim=768, moe_head=12, sie_coe=3.0)
     sd = O.init_state_dict(spec, seed=1)
-    x, cam = synth_batch(2, 256, 128, 4)
+    x, cam = synth_batch(2, h, w, cams)
     target = torch.tensor([0, 0])
     if mode == "train":
         sd = {k: v.requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
@@ -197,7 +217,7 @@ def cpu_baseline(mode, seconds, fusion="atmoe"):
         if dt >= seconds and n >= 2:
             break
     return {"value": round(2 * n / dt, 2), "unit": "tri-modal images/s (1 image = one RGB+NIR+TIR triplet)", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} {'fwd+bwd' if mode == 'train' else 'eval forward'} passes of the fp32 CPU oracle, RGBNT201 " + ("DeMo" if fusion == "atmoe" else "DGAF-V3") + f" config, B=2 "
+            "sample": f"{n} {'fwd+bwd' if mode == 'train' else 'eval forward'} passes of the fp32 CPU oracle, {config} " + ("DeMo" if fusion == "atmoe" else "DGAF-V3") + f" config, B=2 "
                       f"({dt:.1f} s)"}
 
 
@@ -275,26 +295,31 @@ def main():
     dev = torch.device("cuda", local)
     mode = a.mode if a.mode != "auto" else ("train" if have_backward() else "fwd")
     B = a.batch or (128 if mode == "train" else 64)
-    B_TRAFFIC_VALID[0] = mode == "train" and B == 128 and a.dtype == "bf16" and a.fusion == "atmoe"
+    B_TRAFFIC_VALID[0] = mode == "train" and B == 128 and a.dtype == "bf16" and a.fusion == "atmoe" and a.config == "RGBNT201"
 
     # the measured path imports nothing from oracle/ (or tests/): configuration, weights (the modules' own seeded random
     # initialisation -- there are no pretrained files offline) and the synthetic batch are made here
     from demo2_amd.config import get_defaults
     from demo2_amd.modeling import make_model
     cfg = get_defaults()
-    cfg.merge_from_file(os.path.join(ROOT, "demo2_amd", "configs", "RGBNT201", "DeMo.yml"))
+    cfg.merge_from_file(os.path.join(ROOT, "demo2_amd", "configs", "RGBNT100" if a.config == "RGBNT100" else "RGBNT201", "DeMo.yml"))
+    n_cls, n_cam = (50, 8) if a.config == "RGBNT100" else (171, 4)       # dataset statistics: SURVEY.md section 8, config symbols
+    if a.config == "vit":                                                  # config V: config/defaults.py:86,89
+        cfg.MODEL.TRANSFORMER_TYPE, cfg.MODEL.HEAD, cfg.MODEL.SIE_COE = "vit_base_patch16_224", 12, 3.0
     if a.fusion == "dgaf":
         cfg.MODEL.HDM, cfg.MODEL.ATM, cfg.MODEL.USE_DGAF = False, False, True
+    img_h, img_w = cfg.INPUT.SIZE_TRAIN
+    per_id = int(cfg.DATALOADER.NUM_INSTANCE)
     torch.manual_seed(1234)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):     # make_model prints the reference's banner: stdout carries ONLY the JSON line
-        model = make_model(cfg, 171, 4, 0)
+        model = make_model(cfg, n_cls, n_cam, 0)
     model = model.to(dev).set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
     gen = torch.Generator().manual_seed(1234 + rank)                      # SOLVER.SEED (config/defaults.py:182)
-    x = {k: torch.randn(B, 3, 256, 128, generator=gen).to(dev) for k in ("RGB", "NI", "TI")}
-    cam = torch.randint(0, 4, (B,), generator=gen).to(dev)
-    # PK-structured labels: NUM_INSTANCE=4 per identity (configs/RGBNT201/DeMo.yml)
-    target = (torch.arange(B, device=dev) // 4 + rank * (B // 4)) % 171
+    x = {k: torch.randn(B, 3, img_h, img_w, generator=gen).to(dev) for k in ("RGB", "NI", "TI")}
+    cam = torch.randint(0, n_cam, (B,), generator=gen).to(dev)
+    # PK-structured labels: NUM_INSTANCE per identity (configs/*/DeMo.yml)
+    target = (torch.arange(B, device=dev) // per_id + rank * max(1, B // per_id)) % n_cls
 
     if mode == "train":
         from demo2_amd.modeling.hip_backward import TrainStep
@@ -366,7 +391,7 @@ def main():
         dt = float(t.item())
 
     log(f"timed region: {dt:.3f} s for {a.steps} steps")
-    roof = cpu = eager = None
+    roof = cpu = cpu_fwd = eager = None
     if rank == 0:
         # the instrumented extra step runs on rank 0 ONLY: it must not issue collectives the other ranks never join
         saved_sync = getattr(model, "grad_sync", None)
@@ -377,30 +402,44 @@ def main():
             model.grad_sync = saved_sync
         log("roofline pass done; cpu baseline next")
         if world == 1 and not a.no_cpu_baseline:
-            cpu = cpu_baseline(mode, a.cpu_seconds, a.fusion)
+            cpu = cpu_baseline(mode, a.cpu_seconds, a.fusion, a.config)
+            if mode == "train":
+                # BASELINE.json configs[0]: the reference's own CPU-runnable case is the FORWARD on B=2 batches (4 triplets and more)
+                cpu_fwd = cpu_baseline("fwd", max(4.0, a.cpu_seconds / 2), a.fusion, a.config)
         if world == 1 and a.eager_baseline and a.fusion == "atmoe":
             eager = eager_gpu_baseline(mode, B, dev)
     if rank == 0:
         ms = dt / a.steps * 1e3
         val = B * world * a.steps / dt
-        # SURVEY.md 8(d), config A (HDM counted unfolded, as the survey does); DGAF head: trunk 68.34 G + 0.05 G folded fusion
-        flop_per_triplet = (69.99e9 if a.fusion == "atmoe" else 68.39e9) * (3 if mode == "train" else 1)
+        # config A / B 69.99 G, config V 71.73 G per triplet forward (HDM counted UNFOLDED, as the survey does);
+        # DGAF head: trunk 68.34 G + 0.05 G folded fusion.  `model_tflops_folded` counts the algorithm the kernels execute (HDM in its
+        # folded single-query form): 68.39 G (A / B), 68.14 G (V) per triplet forward.
+        unfolded = {"RGBNT201": 69.99e9, "RGBNT100": 69.99e9, "vit": 71.73e9}[a.config] if a.fusion == "atmoe" else 68.39e9
+        folded = {"RGBNT201": 68.39e9, "RGBNT100": 68.39e9, "vit": 68.14e9}[a.config] if a.fusion == "atmoe" else 68.39e9
+        flop_per_triplet = unfolded * (3 if mode == "train" else 1)
+        flop_folded = folded * (3 if mode == "train" else 1)
         line = {
             "metric": "tri-modal images/sec " + ("fwd+bwd" if mode == "train" else "fwd") + " (ViT-B, RGBNT201 shape)",
             "value": round(val, 1), "unit": "tri-modal images/s (1 image = one RGB+NIR+TIR triplet)", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": (("RGBNT201 DeMo.yml (CLIP ViT-B/16 x3 + PIFE + HDM + ATMoE), " if a.fusion == "atmoe" else
+            "config": {"workload": ((({"RGBNT201": "RGBNT201 DeMo.yml (CLIP ViT-B/16 x3 + PIFE + HDM + ATMoE), ",
+                                       "RGBNT100": "RGBNT100 DeMo.yml (CLIP ViT-B/16 x3 + PIFE + HDM + ATMoE, HEAD 8, DIRECT 0; side line), ",
+                                       "vit": "RGBNT201 geometry with the ImageNet ViT-B/16 trunk (C 768, HEAD 12; side line), "}[a.config])
+                                     if a.fusion == "atmoe" else
                                      "RGBNT201 geometry, DeMo class with MODEL.USE_DGAF (CLIP ViT-B/16 x3 + DGAF-V3), ")
                                     + ("train step fwd+bwd, " if mode == "train" else "eval forward, ")
-                                    + f"3x({B},3,256,128) per GPU, random-init weights"),
+                                    + f"3x({B},3,{img_h},{img_w}) per GPU, random-init weights"),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "mode": mode,
                        "launch": "hipGraph replay" if (mode == "train" and stepper.use_graph) else "eager",
                        "input": "pinned host memory, copied every step (PCIe-inclusive)" if (mode == "train" and a.host_input)
                        else "resident in HBM"},
             "model_tflops": round(val * flop_per_triplet / 1e12, 1),
+            "model_tflops_folded": round(val * flop_folded / 1e12, 1),
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if cpu_fwd is not None:
+            line["cpu_baseline_forward"] = cpu_fwd
         if eager is not None:
             line["eager_gpu_baseline"] = eager
         print(json.dumps(line), flush=True)

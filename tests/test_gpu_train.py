@@ -137,6 +137,96 @@ def test_full_size_train_step_fp32_grads():
         assert e < 5e-3, (n, e)
 
 
+FULL = {
+    # BASELINE.json configs[4] / SURVEY 8 config B: configs/RGBNT100/DeMo.yml:1-12 (128 x 256 images, HEAD 8 -> d = 64 experts, DIRECT 0 ->
+    # per-modality heads classifier_r/n/t, 50 classes, 8 cameras)
+    "B": dict(cfg=lambda: make_cfg("RGBNT100"), classes=50, cams=8, size=(128, 256),
+              names=["BACKBONE.base.conv1.weight", "BACKBONE.cv_embed", "BACKBONE.base.transformer.resblocks.0.attn.in_proj_weight",
+                     "BACKBONE.base.transformer.resblocks.6.mlp.c_proj.weight", "BACKBONE.base.transformer.resblocks.11.ln_1.bias",
+                     "BACKBONE.base.proj", "nir_reduce.1.weight", "tir_reduce.0.weight", "generalFusion.rt.in_proj_weight",
+                     "generalFusion.nt.out_proj.weight", "generalFusion.t_token", "generalFusion.moe.experts.7.expertHead.6.mlp.0.weight",
+                     "generalFusion.moe.experts.0.expertHead.3.mlp.0.bias", "generalFusion.moe.experts.5.expertHead.2.mlp.2.weight",
+                     "generalFusion.moe.gating_network.gate.q_.weight", "generalFusion.moe.gating_network.gate.linear_re.0.weight",
+                     "classifier_moe.weight", "bottleneck_moe.weight", "classifier_r.weight", "classifier_n.weight", "classifier_t.weight",
+                     "bottleneck_r.weight", "bottleneck_t.weight"]),
+    # ImageNet ViT-B/16 trunk (config/defaults.py:86,89: C = 768, HEAD 12 -> d = 64, HDM heads 12, SIE on every token)
+    "V": dict(cfg=lambda: make_cfg("RGBNT201", TRANSFORMER_TYPE="vit_base_patch16_224", HEAD=12, SIE_COE=3.0), classes=171, cams=6,
+              size=(256, 128),
+              names=["BACKBONE.base.patch_embed.proj.weight", "BACKBONE.base.patch_embed.proj.bias", "BACKBONE.base.cls_token",
+                     "BACKBONE.base.pos_embed", "BACKBONE.base.sie_embed", "BACKBONE.base.blocks.0.attn.qkv.weight",
+                     "BACKBONE.base.blocks.4.mlp.fc1.weight", "BACKBONE.base.blocks.11.norm2.weight", "BACKBONE.base.norm.weight",
+                     "rgb_reduce.1.weight", "generalFusion.rnt.in_proj_weight", "generalFusion.rn_token",
+                     "generalFusion.moe.experts.11.expertHead.6.mlp.0.weight", "generalFusion.moe.experts.3.expertHead.0.mlp.2.bias",
+                     "generalFusion.moe.gating_network.gate.k_.weight", "classifier_moe.weight", "classifier.weight", "bottleneck.weight"]),
+}
+
+
+@pytest.mark.parametrize("which", ["B", "V"])
+def test_full_size_train_step_fp32_other_configs(which):
+    """Configs B (RGBNT100 DeMo.yml) and V (ViT-B) at FULL model size, training mode, fp32, B = 4 (2 ids x 2): every output, the loss, a
+    sample of gradients from every stage (incl. a d = 64 expert of the last head and the per-modality heads of DIRECT = 0) and ALL
+    BatchNorm running statistics against torch autograd of the CPU oracle.  (DropPath of the ViT trunk is off here -- its masks come
+    from the kernel RNG: test_vit_drop_path_train_step.)"""
+    f = FULL[which]
+    cfg = f["cfg"]()
+    m, sd = build(cfg, f["classes"], f["cams"], torch.float32)
+    spec = spec_of(m)
+    spec.hdm_dropout = 0.0
+    assert (spec.moe_head, spec.feat_dim // spec.moe_head) == ((8, 64) if which == "B" else (12, 64)) and int(m.direct) == (0 if which == "B" else 1)
+    x, cam = synth_batch(4, f["size"][0], f["size"][1], f["cams"])
+    target = torch.tensor([7, 7, 31, 31])
+    idw, trw = float(cfg.MODEL.ID_LOSS_WEIGHT), float(cfg.MODEL.TRIPLET_LOSS_WEIGHT)
+    out_ref, loss_ref, grads_ref, upd = oracle_step(sd, spec, x, cam, target, idw, trw)
+    out = m({k: v.to(DEV) for k, v in x.items()}, label=target.to(DEV), cam_label=cam.to(DEV))
+    assert len(out) == len(out_ref) == (9 if which == "B" else 5) and out[-1] == 0
+    for a, b in zip(out[:-1], out_ref[:-1]):
+        torch.testing.assert_close(a.detach().cpu(), b.detach(), rtol=5e-4, atol=5e-4)
+    loss = total_loss(out, target.to(DEV), make_loss_fn(cfg))
+    torch.testing.assert_close(loss.detach().cpu(), loss_ref.detach(), rtol=2e-4, atol=2e-4)
+    loss.backward()
+    torch.cuda.synchronize()
+    pd = dict(m.named_parameters())
+    for n in f["names"]:
+        e = rel_err(pd[n].grad.detach().cpu(), grads_ref[n])
+        assert e < 5e-3, (n, e)
+    # whole gradient, every parameter the oracle differentiates
+    num = sum(float((pd[n].grad.detach().cpu() - g).pow(2).sum()) for n, g in grads_ref.items() if pd[n].requires_grad)
+    den = sum(float(g.pow(2).sum()) for n, g in grads_ref.items() if pd[n].requires_grad)
+    assert (num / den) ** 0.5 < 2e-3, (num / den) ** 0.5
+    msd = m.state_dict()
+    assert len(upd) >= (3 * (7 * spec.moe_head + 2 + (3 if which == "B" else 1)))           # running_mean / running_var / num_batches_tracked each
+    for k, v in upd.items():
+        torch.testing.assert_close(msd[k].cpu().to(v.dtype), v, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("which", ["B", "V"])
+def test_bench_size_gradient_accumulation_is_linear_bf16_other_configs(which):
+    """The same configurations at B = 128 in bf16 (the benchmarked mode, `bench.py --config RGBNT100 | vit`), through the
+    size-independent property the full-size config-A test uses: two backward passes accumulate exactly twice the gradient."""
+    f = FULL[which]
+    cfg = f["cfg"]()
+    m, _ = build(cfg, f["classes"], f["cams"], torch.bfloat16)
+    x, cam = synth_batch(128, f["size"][0], f["size"][1], f["cams"], seed=22)
+    xd, camd = {k: v.to(DEV) for k, v in x.items()}, cam.to(DEV)
+    target = (torch.arange(128, device=DEV) // 16) % f["classes"]
+    ts = TrainStep(m, cfg, 1, optimizer=False)
+    m._nbt_flat.zero_()
+    l1 = ts.step(xd, target, camd).item()
+    g1 = m.grad_buffer().clone()
+    l2 = ts.step(xd, target, camd).item()
+    g2 = m.grad_buffer().clone()
+    torch.cuda.synchronize()
+    m.check_errors()
+    assert abs(l1 - l2) < 1e-3 * abs(l1) and torch.isfinite(g1).all() and g1.abs().max() > 0
+    rel = ((g2 - 2 * g1).norm() / (2 * g1).norm()).item()
+    assert rel < 2e-3, rel
+    assert int(m._nbt_flat[0]) == 2
+    # every expert of every head and every per-modality head received a gradient
+    for n, p in m.named_parameters():
+        if p.requires_grad and (".expertHead." in n or n.startswith("classifier")) and n.endswith("weight"):
+            assert p.grad.abs().max() > 0, n
+
+
 def test_graph_replay_matches_eager_steps():
     """TrainStep(graph=True): two eager steps, capture, replays -- the parameters after 5 steps equal those of 5 eager
     steps (dropout off: the two modes draw their masks from different seed sources), Adam's device-side count advances."""
