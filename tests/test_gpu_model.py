@@ -114,33 +114,58 @@ def test_vit_b_full_size_eval():
     torch.testing.assert_close(got.cpu(), want, rtol=5e-4, atol=5e-4)
 
 
-def test_synthetic_map_parity_bf16():
-    """north star: mAP / Rank-1 on a synthetic eval set within +-0.1 of the fp32 CPU path (bf16 HIP features)."""
-    cfg = make_cfg("RGBNT201")
-    m, sd = build(cfg, 171, 4, dtype=torch.bfloat16)
-    spec = spec_of(m)
-    rng = np.random.RandomState(0)
-    ids, per = 8, 4
-    g = torch.Generator().manual_seed(7)
-    protos = {k: torch.randn(ids, 3, 256, 128, generator=g) for k in ("RGB", "NI", "TI")}
+def _synthetic_gallery(ids, per, noise, size, seed=7):
+    """ids x per tri-modal images = a fixed random prototype per identity + noise; cameras alternate inside an identity; shuffled."""
+    g = torch.Generator().manual_seed(seed)
+    protos = {k: torch.randn(ids, 3, size[0], size[1], generator=g) for k in ("RGB", "NI", "TI")}
     pid = np.repeat(np.arange(ids), per)
     camid = np.tile(np.arange(per) % 2, ids)
-    x = {k: protos[k][pid] + 0.8 * torch.randn(ids * per, 3, 256, 128, generator=g) for k in protos}
+    x = {k: protos[k][pid] + noise * torch.randn(ids * per, 3, size[0], size[1], generator=g) for k in protos}
+    order = np.random.RandomState(0).permutation(ids * per)
+    return {k: v[order] for k, v in x.items()}, pid[order], camid[order]
+
+
+def test_synthetic_map_parity():
+    """north star: mAP / Rank-1 on a synthetic eval set within +-0.1 points of the reference CPU path.  SURVEY 8(d) sizes: 30 identities x 4
+    images (2 cameras), 60 queries against 60 gallery items, market1501 protocol (same-pid-same-camera removal), full-size config A.
+    The set is built NOT to be saturated or degenerate: with the seeded random weights the camera (SIE) embedding would dominate the cls
+    token after ln_pre and every ranking would be 'same camera first' (mAP 3.8 %, Rank-1 0 at ANY noise level, measured on the oracle), so
+    these synthetic weights carry a camera embedding scaled by 0.01; the noise level (1.8 x the prototype's std) puts the fp32 oracle at
+    mAP ~ 70 %, Rank-1 ~ 60 % -- asserted to lie inside (20 %, 95 %).  The reference evaluates WITHOUT autocast (engine/processor.py:
+    247-282), i.e. in fp32: the fp32 compute mode is the protocol-faithful one, the bf16 mode (what bench.py --mode fwd times) is held to
+    the same +-0.1."""
+    cfg = make_cfg("RGBNT201")
+    torch.manual_seed(0)
+    m = make_model(cfg, 171, 4, 0)
+    spec = spec_of(m)
+    sd = O.init_state_dict(spec, seed=1)
+    sd["BACKBONE.cv_embed"] = sd["BACKBONE.cv_embed"] * 0.01
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    ids, per, nq = 30, 4, 60
+    x, pid, camid = _synthetic_gallery(ids, per, 1.8, (256, 128))
     cam = torch.tensor(camid)
-    order = rng.permutation(ids * per)
-    x = {k: v[order] for k, v in x.items()}
-    pid, camid, cam = pid[order], camid[order], cam[order]
-    feats_ref, feats_hip = [], []
+    feats = {"oracle": [], torch.float32: [], torch.bfloat16: []}
     for i in range(0, ids * per, 8):
         xb = {k: v[i:i + 8] for k, v in x.items()}
-        feats_ref.append(O.model_forward(sd, spec, xb, cam[i:i + 8]))
-        with torch.no_grad():
-            feats_hip.append(m({k: v.to(DEV) for k, v in xb.items()}, cam_label=cam[i:i + 8].to(DEV)).cpu())
-    nq = 12
-    # eval_func needs >= max_rank kept gallery items per query (utils/metrics.py:149,165): 20 gallery items -> rank 10
-    cmc_r, map_r = O.r1_map(torch.cat(feats_ref), pid, camid, nq, max_rank=10)
-    cmc_h, map_h = O.r1_map(torch.cat(feats_hip), pid, camid, nq, max_rank=10)
+        feats["oracle"].append(O.model_forward(sd, spec, xb, cam[i:i + 8]))
+        xd = {k: v.to(DEV) for k, v in xb.items()}
+        for dt in (torch.float32, torch.bfloat16):
+            with torch.no_grad():
+                feats[dt].append(m.set_compute_dtype(dt)(xd, cam_label=cam[i:i + 8].to(DEV)).cpu())
+    res = {k: O.r1_map(torch.cat(v), pid, camid, nq, max_rank=10) for k, v in feats.items()}
+    (cmc_r, map_r), (cmc_f, map_f), (cmc_h, map_h) = res["oracle"], res[torch.float32], res[torch.bfloat16]
+    print(f"\nsynthetic eval (30 ids x 4, nq 60): mAP / Rank-1 / Rank-5 [%]  oracle fp32 {100 * map_r:.2f} / {100 * cmc_r[0]:.2f} / {100 * cmc_r[4]:.2f}"
+          f"   HIP fp32 {100 * map_f:.2f} / {100 * cmc_f[0]:.2f} / {100 * cmc_f[4]:.2f}   HIP bf16 {100 * map_h:.2f} / {100 * cmc_h[0]:.2f} / {100 * cmc_h[4]:.2f}")
+    assert 0.20 < map_r < 0.95 and 0.20 < cmc_r[0] < 0.95, (map_r, cmc_r[0])          # neither saturated nor degenerate
+    assert abs(map_r - map_f) * 100 <= 0.1 and abs(cmc_r[0] - cmc_f[0]) * 100 <= 0.1, (map_r, map_f, cmc_r[0], cmc_f[0])
     assert abs(map_r - map_h) * 100 <= 0.1 and abs(cmc_r[0] - cmc_h[0]) * 100 <= 0.1, (map_r, map_h, cmc_r[0], cmc_h[0])
+    # the GPU evaluator on the GPU features gives the same figures as the numpy protocol on them
+    from demo2_amd.utils.metrics import R1_mAP_eval
+    ev = R1_mAP_eval(nq, max_rank=10, feat_norm="yes")
+    ev.update((torch.cat(feats[torch.bfloat16]).to(DEV), pid.tolist(), camid.tolist(), [str(i) for i in range(ids * per)]))
+    out = ev.compute()
+    assert abs(out[1] - map_h) < 1e-5 and abs(float(out[0][0]) - float(cmc_h[0])) < 1e-6
 
 
 def test_bench_size_properties_bf16():
