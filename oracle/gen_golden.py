@@ -261,7 +261,101 @@ def gen_eval(tag="evalfunc"):
           cmc=cmc, mAP=np.asarray(mAP))
 
 
+def _toy_dataset(rng, n_ids, lo, hi):
+    """(path, pid, camid, viewid) tuples as data/datasets/bases.py yields them; identities interleaved, some with fewer than K samples."""
+    items = []
+    for pid in rng.permutation(n_ids):
+        for j in range(int(rng.randint(lo, hi + 1))):
+            items.append(("", int(pid) * 3 + 1, int(j % 4), 0))
+    order = rng.permutation(len(items))
+    return [items[i] for i in order]
+
+
+def gen_sampler(tag="sampler_legacy"):
+    """Index sequences of the reference's OWN sampler classes (data/datasets/sampler.py:8-67, sampler_ddp.py:117-201) for seeded global
+    `random` / `np.random` states (train_net.py:18-30 seeds both with SOLVER.SEED): two epochs of the single-process sampler, and the
+    data-parallel sampler's global list plus every rank's part for world sizes 1, 2 and 4.  The data-parallel class asks
+    torch.distributed for rank / world size in its constructor, so it is built inside a one-rank gloo group and the (rank, world,
+    mini-batch) attributes are then set to each partition in turn -- its own __fetch_current_node_idxs does the cutting."""
+    import random
+    import tempfile
+    import torch.distributed as dist
+    sm = _load("ref_sampler", "data/datasets/sampler.py")
+    sd = _load("ref_sampler_ddp", "data/datasets/sampler_ddp.py")
+    data = _toy_dataset(np.random.RandomState(5), 23, 2, 11)
+    out = {"pids": np.asarray([d[1] for d in data]), "seed": np.asarray(1234)}
+    for (bs, k) in ((16, 4), (24, 8)):
+        random.seed(1234)
+        np.random.seed(1234)
+        s = sm.RandomIdentitySampler(data, bs, k)
+        out[f"single_b{bs}_k{k}_len"] = np.asarray(len(s))
+        out[f"single_b{bs}_k{k}_e0"] = np.asarray([int(i) for i in s])
+        out[f"single_b{bs}_k{k}_e1"] = np.asarray([int(i) for i in s])          # second epoch: the global states have moved on
+    with tempfile.TemporaryDirectory() as tmp:
+        dist.init_process_group("gloo", init_method="file://" + os.path.join(tmp, "pg"), rank=0, world_size=1)
+        try:
+            for (bs, k) in ((16, 4), (32, 4)):
+                for world in (1, 2, 4):
+                    s = sd.RandomIdentitySampler_DDP(data, bs, k)
+                    s.world_size = world
+                    s.mini_batch_size = bs // world
+                    s.num_pids_per_batch = s.mini_batch_size // k
+                    np.random.seed(1234)
+                    seed = int(np.random.randint(2 ** 31))                     # shared_random_seed() of a one-rank group (:103-114)
+                    np.random.seed(seed)
+                    full = [int(i) for i in s.sample_list()]
+                    out[f"ddp_b{bs}_k{k}_w{world}_seed"] = np.asarray(seed)
+                    out[f"ddp_b{bs}_k{k}_w{world}_global"] = np.asarray(full)
+                    length = int(np.ceil(len(full) * 1.0 / world))
+                    for r in range(world):
+                        s.rank = r
+                        part = s._RandomIdentitySampler_DDP__fetch_current_node_idxs(full, length)
+                        out[f"ddp_b{bs}_k{k}_w{world}_r{r}"] = np.asarray([int(i) for i in part])
+            # the class's own __iter__ end to end (world 1), second call included
+            np.random.seed(77)
+            s = sd.RandomIdentitySampler_DDP(data, 16, 4)
+            out["ddp_iter_e0"] = np.asarray([int(i) for i in s])
+            out["ddp_iter_e1"] = np.asarray([int(i) for i in s])
+        finally:
+            dist.destroy_process_group()
+    _save(tag, **out)
+
+
+def gen_eval_msrv(tag="evalfunc_msrv"):
+    """eval_func_msrv / R1_mAP (utils/metrics.py:12-107,172-218): the MSVR310 protocol (same identity AND same scene removed).  The
+    reference writes a rank list to ./re.txt while it evaluates, so this runs inside a temporary directory."""
+    import tempfile
+    try:
+        met = load_reference_metrics()
+    except Exception as e:
+        print("skip msrv fixture:", repr(e))
+        return
+    rng = np.random.RandomState(3)
+    nq, ng, D, ids = 40, 260, 32, 12
+    q_p, g_p = rng.randint(0, ids, nq), rng.randint(0, ids, ng)
+    q_c, g_c = rng.randint(0, 8, nq), rng.randint(0, 8, ng)
+    q_s, g_s = rng.randint(0, 3, nq), rng.randint(0, 3, ng)
+    cent = rng.randn(ids, D)
+    feats = torch.tensor(np.concatenate([cent[q_p], cent[g_p]]) + rng.randn(nq + ng, D) * 1.6, dtype=torch.float32)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            ev = met.R1_mAP(nq, max_rank=50, feat_norm='yes')
+            ev.reset()
+            ev.update((feats, np.concatenate([q_p, g_p]), np.concatenate([q_c, g_c]), np.concatenate([q_s, g_s]), [""] * (nq + ng)))
+            cmc, mAP = ev.compute()[:2]
+        finally:
+            os.chdir(cwd)
+    _save(tag, feats=feats, pids=np.concatenate([q_p, g_p]), camids=np.concatenate([q_c, g_c]), sceneids=np.concatenate([q_s, g_s]),
+          nq=np.asarray(nq), cmc=cmc, mAP=np.asarray(mAP))
+
+
 def main():
+    if len(sys.argv) > 1:                                  # e.g. `python oracle/gen_golden.py gen_sampler gen_eval_msrv`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        return
     ref = load_reference()
     gen_fusion(ref)
     gen_fusion(ref, C=64, H=2, n_tok=5, tag="fusion_c64_h2", with_grads=True)
@@ -271,6 +365,8 @@ def main():
     gen_losses(ref)
     gen_eval()
     gen_dgaf()
+    gen_sampler()
+    gen_eval_msrv()
 
 
 if __name__ == "__main__":

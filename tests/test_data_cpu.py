@@ -182,3 +182,59 @@ def test_device_feeder_cpu_device():
         for g, w in zip(got[1:], want[1:]):
             assert torch.equal(g, w) if torch.is_tensor(w) else g == w
     assert list(DeviceFeeder([], "cpu")) == []
+
+
+# ---- legacy_rng: the reference's index sequence bit for bit (fixture written by the reference's own classes) -------
+def _fixture_dataset(g):
+    return [("", int(p), 0, 0) for p in g["pids"].tolist()]
+
+
+@pytest.mark.parametrize("bs,k", [(16, 4), (24, 8)])
+def test_legacy_rng_single_process_sequence_equals_the_reference(golden, bs, k):
+    import random
+    from demo2_amd.data import RandomIdentitySampler as S
+    g = golden("sampler_legacy")
+    data = _fixture_dataset(g)
+    seed = int(g["seed"])
+    random.seed(seed)                                            # train_net.py:18-30 seeds both global generators with SOLVER.SEED
+    np.random.seed(seed)
+    s = S(data, bs, k, legacy_rng=True)
+    assert len(s) == int(g[f"single_b{bs}_k{k}_len"])
+    e0, e1 = list(s), list(s)
+    assert e0 == g[f"single_b{bs}_k{k}_e0"].tolist()
+    assert e1 == g[f"single_b{bs}_k{k}_e1"].tolist()              # the second epoch continues from the advanced global states
+    assert e0 != e1
+    with pytest.raises(ValueError):
+        S(data, bs, k, seed=3, legacy_rng=True)
+
+
+@pytest.mark.parametrize("bs,k", [(16, 4), (32, 4)])
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_legacy_rng_data_parallel_sequence_equals_the_reference(golden, bs, k, world):
+    from demo2_amd.data import RandomIdentitySampler_DDP as S
+    from demo2_amd.data.sampler import _legacy_global_order
+    g = golden("sampler_legacy")
+    data = _fixture_dataset(g)
+    parts = []
+    for r in range(world):
+        np.random.seed(int(g["seed"]))
+        s = S(data, bs, k, rank=r, world_size=world, legacy_rng=True)
+        mine = list(s)
+        assert s._seed_used == int(g[f"ddp_b{bs}_k{k}_w{world}_seed"])
+        assert mine == g[f"ddp_b{bs}_k{k}_w{world}_r{r}"].tolist(), (r, world)
+        assert len(s) == len(mine)
+        parts.append(mine)
+    np.random.seed(int(g[f"ddp_b{bs}_k{k}_w{world}_seed"]))
+    s = S(data, bs, k, rank=0, world_size=world, legacy_rng=True)
+    assert _legacy_global_order(s.index_dic, s.num_pids_per_batch, k) == g[f"ddp_b{bs}_k{k}_w{world}_global"].tolist()
+    assert len(set(map(len, parts))) == 1                        # here every rank gets the same number of whole mini-batches
+
+
+def test_legacy_rng_data_parallel_iter_end_to_end(golden):
+    """The reference class's own __iter__ (seed draw from np.random.randint, np.random.seed, sample_list, block selection), two epochs."""
+    from demo2_amd.data import RandomIdentitySampler_DDP as S
+    g = golden("sampler_legacy")
+    np.random.seed(77)
+    s = S(_fixture_dataset(g), 16, 4, rank=0, world_size=1, legacy_rng=True)
+    assert list(s) == g["ddp_iter_e0"].tolist()
+    assert list(s) == g["ddp_iter_e1"].tolist()

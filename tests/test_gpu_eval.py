@@ -69,6 +69,18 @@ def test_msvr310_scene_protocol():
     assert abs(mAP2 - map_ref) < 1e-6
 
 
+def test_msvr310_protocol_matches_reference_golden(golden):
+    """The GPU evaluator's R1_mAP / eval_func_msrv against the fixture the reference's own R1_mAP.compute produced
+    (tests/golden/evalfunc_msrv.npz, oracle/gen_golden.py: gen_eval_msrv)."""
+    g = golden("evalfunc_msrv")
+    nq = int(g["nq"])
+    ev = R1_mAP(nq, max_rank=50, feat_norm="yes")
+    ev.update((g["feats"].to(DEV), g["pids"].numpy(), g["camids"].numpy(), g["sceneids"].numpy(), None))
+    cmc, mAP, *_ = ev.compute()
+    np.testing.assert_allclose(cmc, g["cmc"].numpy(), atol=1e-6)
+    assert abs(mAP - float(g["mAP"])) < 1e-6
+
+
 def test_rank_eval_properties():
     """Bit-exact index work: the returned order is a permutation that sorts each row (ties by index), AP = 1 when every
     match precedes every non-match, and queries whose identity is absent are flagged."""

@@ -92,6 +92,20 @@ def test_eval_func(golden):
     assert abs(mAP - float(g["mAP"])) < 1e-6
 
 
+def test_eval_func_msrv(golden):
+    """MSVR310 protocol (utils/metrics.py:12-107,172-218): the oracle reads eval_func_msrv as eval_func with the SCENE id in the role
+    of the camera id (removal of same-identity-same-scene gallery items, :67 against :140); pinned here by the output of the
+    reference's own R1_mAP.compute on a seeded feature set (oracle/gen_golden.py: gen_eval_msrv)."""
+    g = golden("evalfunc_msrv")
+    nq = int(g["nq"])
+    cmc, mAP = O.r1_map(g["feats"], g["pids"].numpy(), g["sceneids"].numpy(), nq)
+    np.testing.assert_allclose(cmc, g["cmc"].numpy(), rtol=1e-6)
+    assert abs(mAP - float(g["mAP"])) < 1e-6
+    # and the camera ids really play no part: the market1501 removal rule gives a different answer on this set
+    cmc_cam, map_cam = O.r1_map(g["feats"], g["pids"].numpy(), g["camids"].numpy(), nq)
+    assert abs(map_cam - float(g["mAP"])) > 1e-4
+
+
 def test_model_forward_shapes():
     spec = O.Spec(arch="clip", img_h=64, img_w=32, width=128, layers=2, heads=2, feat_dim=64, moe_head=2,
                   num_classes=11, camera_num=3)
