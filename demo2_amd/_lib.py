@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(_HERE, "..", "include", "demo_hip.h")
 
 F32, BF16 = 0, 1
 ERR_CAM_RANGE, ERR_LABEL_RANGE = 1, 2          # include/demo_hip.h: bits of the device error word
-ACT_NONE, ACT_QUICKGELU, ACT_GELU = 0, 1, 2
+ACT_NONE, ACT_QUICKGELU, ACT_GELU, ACT_SAVED = 0, 1, 2, 3      # ACT_SAVED: only as act_grad_kind (the operand is the derivative)
 
 
 class DemoHipError(RuntimeError):
@@ -34,7 +34,7 @@ class GemmDesc(C.Structure):
         ("sA1", C.c_int64), ("sA2", C.c_int64), ("sB1", C.c_int64), ("sB2", C.c_int64),
         ("sC1", C.c_int64), ("sC2", C.c_int64), ("sBias1", C.c_int64), ("sBias2", C.c_int64),
         ("act_grad_pre", C.c_void_p), ("dtPre", C.c_int32), ("act_grad_kind", C.c_int32), ("accumulate", C.c_int32),
-        ("pre_out", C.c_void_p),
+        ("pre_out", C.c_void_p), ("pre_out_kind", C.c_int32),
     ]
 
 

@@ -121,7 +121,25 @@ __device__ __forceinline__ float act_grad(float x, int act) {
     float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
     return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
   }
+  if (act == DEMO_ACT_SAVED) return x;          // the operand already is the derivative (saved by the forward, pre_out_kind 1)
   return 1.0f;
+}
+
+// activation and its derivative from ONE evaluation of the shared transcendental part (forward epilogues that save act'(x))
+__device__ __forceinline__ float act_both(float x, int act, float& d) {
+  if (act == DEMO_ACT_QUICKGELU) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+    const float u = x * s;
+    d = fmaf(1.702f * u, 1.0f - s, s);          // s (1 + 1.702 x (1 - s))
+    return u;
+  }
+  if (act == DEMO_ACT_GELU) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    d = fmaf(x * 0.3989422804014327f, __expf(-0.5f * x * x), cdf);
+    return x * cdf;
+  }
+  d = 1.0f;
+  return x;
 }
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

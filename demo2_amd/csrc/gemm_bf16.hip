@@ -30,6 +30,7 @@ struct FArgs {
   const float* residual;
   const void* pre;
   void* pre_out;
+  int pre_out_kind;            // 0: pre-activation, 1: act'(pre-activation)
   int M, N, K;
   int64_t lda, ldb, ldc;
   int64_t sA, sB, sC, sBias;   // batch strides (single level)
@@ -93,10 +94,15 @@ __device__ __forceinline__ void epi4(const FArgs& p, const float4 b4, int64_t co
   v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
   const int64_t ci = coff + (int64_t)m * p.ldc + n;
   if (p.pre_out) {
-    if (p.dtC == DEMO_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.pre_out) + ci) = make_float4(v[0], v[1], v[2], v[3]);
-    else io<bf16_t>::st4(reinterpret_cast<bf16_t*>(p.pre_out) + ci, make_float4(v[0], v[1], v[2], v[3]));
+    float s[4] = {v[0], v[1], v[2], v[3]};
+    if (p.pre_out_kind == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = act_both(v[e], p.act, s[e]);
+    }
+    if (p.dtC == DEMO_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.pre_out) + ci) = make_float4(s[0], s[1], s[2], s[3]);
+    else io<bf16_t>::st4(reinterpret_cast<bf16_t*>(p.pre_out) + ci, make_float4(s[0], s[1], s[2], s[3]));
   }
-  if (p.act != DEMO_ACT_NONE) {
+  if (p.act != DEMO_ACT_NONE && !(p.pre_out && p.pre_out_kind == 1)) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act);
   }
@@ -157,16 +163,25 @@ __device__ __forceinline__ void epi8_finish(const FArgs& p, const float4 bz0, co
   const bool has_pre = GK >= 0 ? GK != DEMO_ACT_NONE : p.pre != nullptr;
   v[0] += bz0.x; v[1] += bz0.y; v[2] += bz0.z; v[3] += bz0.w;
   v[4] += bz1.x; v[5] += bz1.y; v[6] += bz1.z; v[7] += bz1.w;
+  const bool save_deriv = p.pre_out && p.pre_out_kind == 1;
   if (p.pre_out) {
+    float s[8];
+    if (save_deriv) {                                      // activation and its derivative from one exp / rcp (or erf) per element
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = act_both(v[e], act, s[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] = v[e];
+    }
     if (p.dtC == DEMO_F32) {
       float* q = reinterpret_cast<float*>(p.pre_out) + ci;
-      *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<float4*>(q + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      *reinterpret_cast<float4*>(q) = make_float4(s[0], s[1], s[2], s[3]);
+      *reinterpret_cast<float4*>(q + 4) = make_float4(s[4], s[5], s[6], s[7]);
     } else {
-      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.pre_out) + ci) = f32x8_to_bf16(v);
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.pre_out) + ci) = f32x8_to_bf16(s);
     }
   }
-  if (act != DEMO_ACT_NONE) {
+  if (act != DEMO_ACT_NONE && !save_deriv) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e], act);
   }
@@ -285,6 +300,8 @@ __device__ __forceinline__ void epi_rows(const FArgs& p, const float* __restrict
     epi_rows_k<NIT, RSTEP, BN_, G, DEMO_ACT_GELU, DEMO_ACT_NONE>(p, ct, r0, mrow0, n, c, bz0, bz1, coff, epre, have_epre);
   else if (p.act == DEMO_ACT_NONE && gk == DEMO_ACT_GELU)
     epi_rows_k<NIT, RSTEP, BN_, G, DEMO_ACT_NONE, DEMO_ACT_GELU>(p, ct, r0, mrow0, n, c, bz0, bz1, coff, epre, have_epre);
+  else if (p.act == DEMO_ACT_NONE && gk == DEMO_ACT_SAVED)
+    epi_rows_k<NIT, RSTEP, BN_, G, DEMO_ACT_NONE, DEMO_ACT_SAVED>(p, ct, r0, mrow0, n, c, bz0, bz1, coff, epre, have_epre);
   else
     epi_rows_k<NIT, RSTEP, BN_, G, -1, -1>(p, ct, r0, mrow0, n, c, bz0, bz1, coff, epre, have_epre);
 }
@@ -394,6 +411,8 @@ __device__ __forceinline__ void pp_epi(const FArgs& p, const f32x4 (&acc)[8][4],
     pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_QUICKGELU, 2>(p, acc, mrow, ncol, coff, bias);   // MLP backward: (dY W2^T) * act'(pre)
   } else if (p.pre && p.dtPre == DEMO_BF16 && !p.residual && !old && p.act == DEMO_ACT_NONE && gk == DEMO_ACT_GELU) {
     pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_GELU, 2>(p, acc, mrow, ncol, coff, bias);
+  } else if (p.pre && p.dtPre == DEMO_BF16 && !p.residual && !old && p.act == DEMO_ACT_NONE && gk == DEMO_ACT_SAVED) {
+    pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_SAVED, 2>(p, acc, mrow, ncol, coff, bias);       // MLP backward on a saved derivative: one multiply
   } else {
     pp_epi_k<1, -1, -1, -1>(p, acc, mrow, ncol, coff, bias);
   }
@@ -914,6 +933,7 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
   p.residual = d.residual;
   p.pre = d.act_grad_pre;
   p.pre_out = d.pre_out;
+  p.pre_out_kind = d.pre_out ? d.pre_out_kind : 0;
   p.M = d.M; p.N = d.N; p.K = d.K;
   p.lda = d.a_rs; p.ldb = d.b_rs; p.ldc = d.c_rs;
   const bool lvl1 = d.batch1 != 1;

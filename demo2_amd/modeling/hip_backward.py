@@ -469,7 +469,8 @@ def trunk_backward(m, tape, dtokens):
             d_res, rbuf = ops.rowscale_cast(dx, s["dp_m"], Bn, L, T), None
         # x2 = x1 + drop_path(fc2(u))
         dw(d_res, s["u"], k["fc2_w"], 4 * W, k["fc2_b"], buf=rbuf)
-        dpre = ops.gemm(d_res, P.wt(k["fc2_w"], T), act_grad_pre=s["pre"], act_grad_kind=act)      # (M, 4W) = (dx W2) * act'(pre)
+        dpre = ops.gemm(d_res, P.wt(k["fc2_w"], T), act_grad_pre=s["pre"],                          # (M, 4W) = (dx W2) * act'(pre)
+                        act_grad_kind=ops.ACT_SAVED if s.get("pre_deriv") else act)
         # u = act(fc1(h2))
         dw(dpre, s["h2"], k["fc1_w"], W, k["fc1_b"])
         dh2 = ops.gemm(dpre, P.wt(k["fc1_w"], T))                                                  # (M, W)

@@ -75,6 +75,9 @@ def trunk_forward(m, imgs: List[Tensor], cam: Optional[Tensor], T: torch.dtype, 
     if T == torch.bfloat16 and m.bf16_fwd_stream and m.bf16_grad_stream and g.arch == "clip":
         return _trunk_blocks_bf16_stream(m, x, Bn, L, W, act, tape)
     # ---- K3-K6: transformer blocks -------------------------------------------------------------------
+    # bf16 mode: fc1's epilogue saves act'(pre) instead of pre (both from one exp / rcp), so the backward product (dY W2^T) * act'
+    # multiplies by a saved tensor instead of re-evaluating the derivative (GEMM epilogue VALU: ~10 -> 3 instructions per element)
+    deriv = bool(m.save_act_deriv and T == torch.bfloat16)
     for i in range(g.layers):
         k = g.block_keys(i)
         sv = tape is not None
@@ -98,7 +101,7 @@ def trunk_forward(m, imgs: List[Tensor], cam: Optional[Tensor], T: torch.dtype, 
         h2 = r3[0] if sv else r3
         if sv:
             pre = torch.empty(Bn * L, 4 * W, device=dev, dtype=T)
-            u = ops.gemm(h2, P.w(k["fc1_w"], T), bias=P.f(k["fc1_b"]), act=act, pre_out=pre)
+            u = ops.gemm(h2, P.w(k["fc1_w"], T), bias=P.f(k["fc1_b"]), act=act, pre_out=pre, pre_out_deriv=deriv)
         else:
             pre = None
             u = ops.gemm(h2, P.w(k["fc1_w"], T), bias=P.f(k["fc1_b"]), act=act)
@@ -108,7 +111,7 @@ def trunk_forward(m, imgs: List[Tensor], cam: Optional[Tensor], T: torch.dtype, 
             x2 = ops.rowscale_add(x1, ops.gemm(u, P.w(k["fc2_w"], T), bias=P.f(k["fc2_b"])), dp_m, Bn, L, out=None if sv else x1)
         if sv:
             tape.blocks.append(dict(x=x, mean1=r1[1], rstd1=r1[2], h1=h1, qkv=qkv, lse=r2[1], a=a, x1=x1, mean2=r3[1], rstd2=r3[2],
-                                    h2=h2, pre=pre, u=u, dp_a=dp_a, dp_m=dp_m))
+                                    h2=h2, pre=pre, pre_deriv=deriv, u=u, dp_a=dp_a, dp_m=dp_m))
         x = x2
     # ---- K7: final LayerNorm (+ CLIP projection) ---------------------------------------------------------
     sv = tape is not None
@@ -138,6 +141,7 @@ def _trunk_blocks_bf16_stream(m, x32: Tensor, Bn: int, L: int, W: int, act: int,
     T = torch.bfloat16
     dev = x32.device
     sv = tape is not None
+    deriv = bool(m.save_act_deriv)
     xs = ops.cast_f32_bf16(x32.view(-1), torch.empty(x32.numel(), device=dev, dtype=T)).view_as(x32)
     pend = None                                            # branch output still to be added to the stream
     for i in range(g.layers):
@@ -155,14 +159,14 @@ def _trunk_blocks_bf16_stream(m, x32: Tensor, Bn: int, L: int, W: int, act: int,
         h2 = r3[0] if sv else r3
         if sv:
             pre = torch.empty(Bn * L, 4 * W, device=dev, dtype=T)
-            u = ops.gemm(h2, P.w(k["fc1_w"], T), bias=P.f(k["fc1_b"]), act=act, pre_out=pre)
+            u = ops.gemm(h2, P.w(k["fc1_w"], T), bias=P.f(k["fc1_b"]), act=act, pre_out=pre, pre_out_deriv=deriv)
         else:
             pre = None
             u = ops.gemm(h2, P.w(k["fc1_w"], T), bias=P.f(k["fc1_b"]), act=act)
         pend = ops.gemm(u, P.w(k["fc2_w"], T), bias=P.f(k["fc2_b"]))
         if sv:
             tape.blocks.append(dict(x=x_in, mean1=r1[1], rstd1=r1[2], h1=h1, qkv=qkv, lse=r2[1], a=a, x1=x1, mean2=r3[1], rstd2=r3[2],
-                                    h2=h2, pre=pre, u=u, dp_a=None, dp_m=None))
+                                    h2=h2, pre=pre, pre_deriv=deriv, u=u, dp_a=None, dp_m=None))
         xs = x1
     x_final = torch.empty_like(xs) if sv else xs
     rf = ops.layernorm_add_fwd(xs, pend, P.f(g.k_lnpost + ".weight"), P.f(g.k_lnpost + ".bias"), g.ln_eps, xsum_out=x_final, save=sv)

@@ -10,7 +10,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_QUICKGELU, BF16, F32, GemmDesc, check
+from ._lib import ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_SAVED, BF16, F32, GemmDesc, check
 
 Tensor = torch.Tensor
 
@@ -87,7 +87,7 @@ def gemm_raw(A: Tensor, B: Tensor, Cout: Tensor, M: int, N: int, K: int, a_rs: i
              c_rs: int, *, a_off: int = 0, b_off: int = 0, c_off: int = 0, bias: Optional[Tensor] = None, bias_off: int = 0,
              residual: Optional[Tensor] = None, act: int = ACT_NONE, alpha: float = 1.0, batch1: int = 1, batch2: int = 1,
              sA=(0, 0), sB=(0, 0), sC=(0, 0), sBias=(0, 0), act_grad_pre: Optional[Tensor] = None, act_grad_kind: int = 0,
-             accumulate: bool = False, pre_out: Optional[Tensor] = None):
+             accumulate: bool = False, pre_out: Optional[Tensor] = None, pre_out_deriv: bool = False):
     """Fully explicit descriptor launch; offsets are in elements of the respective tensor."""
     _req_cuda(A, B, Cout, bias, residual, act_grad_pre)
     d = GemmDesc()
@@ -127,6 +127,7 @@ def gemm_raw(A: Tensor, B: Tensor, Cout: Tensor, M: int, N: int, K: int, a_rs: i
         d.pre_out = pre_out.data_ptr() + c_off * pre_out.element_size()
     else:
         d.pre_out = None
+    d.pre_out_kind = 1 if (pre_out is not None and pre_out_deriv) else 0
     check(_lib.load().demo_gemm(C.byref(d), _stream()), "demo_gemm")
     return Cout
 
@@ -134,8 +135,10 @@ def gemm_raw(A: Tensor, B: Tensor, Cout: Tensor, M: int, N: int, K: int, a_rs: i
 def gemm(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
          bias: Optional[Tensor] = None, residual: Optional[Tensor] = None, act: int = ACT_NONE, alpha: float = 1.0,
          act_grad_pre: Optional[Tensor] = None, act_grad_kind: int = 0, accumulate: bool = False,
-         pre_out: Optional[Tensor] = None, pre_out_new: bool = False):
-    """out[M,N] = act(alpha * a[M,K] @ b[N,K]^T + bias) (* act'(pre)) (+ residual).  a, b may be any 2-D strided views."""
+         pre_out: Optional[Tensor] = None, pre_out_new: bool = False, pre_out_deriv: bool = False):
+    """out[M,N] = act(alpha * a[M,K] @ b[N,K]^T + bias) (* act'(pre)) (+ residual).  a, b may be any 2-D strided views.
+    pre_out receives the pre-activation, or its activation DERIVATIVE with pre_out_deriv (then the backward product takes
+    act_grad_kind=ACT_SAVED: one multiply instead of re-evaluating act' from the pre-activation)."""
     assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1], (a.shape, b.shape)
     M, K = a.shape
     N = b.shape[0]
@@ -152,7 +155,7 @@ def gemm(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, out_dtype: Optio
         assert pre_out.shape == (M, N) and pre_out.stride() == out.stride()
     gemm_raw(a, b, out, M, N, K, a.stride(0), a.stride(1), b.stride(0), b.stride(1), out.stride(0), bias=bias,
              residual=residual, act=act, alpha=alpha, act_grad_pre=act_grad_pre, act_grad_kind=act_grad_kind,
-             accumulate=accumulate, pre_out=pre_out)
+             accumulate=accumulate, pre_out=pre_out, pre_out_deriv=pre_out_deriv)
     return (out, pre_out) if pre_out_new else out
 
 

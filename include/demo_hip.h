@@ -29,6 +29,7 @@ extern "C" {
 #define DEMO_ACT_NONE 0
 #define DEMO_ACT_QUICKGELU 1 /* x*sigmoid(1.702x): modeling/clip/model.py:163-165, modeling/moe/AttnMOE.py:5-7 */
 #define DEMO_ACT_GELU 2      /* erf GELU: modeling/backbones/vit_pytorch.py:126 (nn.GELU) */
+#define DEMO_ACT_SAVED 3     /* only as act_grad_kind: the tensor act_grad_pre IS the derivative (a forward saved it: pre_out_kind 1) */
 
 int demo_abi_version(void);
 const char* demo_last_error(void); /* thread-local, host pointer */
@@ -62,6 +63,9 @@ typedef struct demo_gemm_desc {
   int32_t act_grad_kind;  /* DEMO_ACT_* whose derivative is applied */
   int32_t accumulate;     /* 1: C += result (fp32 C only) */
   void* pre_out;          /* optional: value BEFORE `act` (after alpha, bias), indexed and typed like C; saved for backward */
+  int32_t pre_out_kind;   /* what pre_out receives: 0 = that pre-activation x, 1 = act'(x).  With 1 the backward product's epilogue is one
+                             multiply (act_grad_kind DEMO_ACT_SAVED) instead of re-evaluating the derivative from x: the exponential and
+                             the reciprocal are computed once, in the forward, where sigmoid(1.702x) / erf are needed anyway */
 } demo_gemm_desc;
 int demo_gemm(const demo_gemm_desc* d, void* stream);
 /* what demo_gemm would pick: 0 = generic fp32-FMA kernel, 1 = bf16 MFMA 128x128 kernel, 2 = bf16 MFMA 256x256 ping-pong kernel */

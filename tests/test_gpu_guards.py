@@ -37,7 +37,7 @@ def test_out_of_range_camera_id_is_reported_and_reads_nothing_outside_the_table(
         good = m(xd, cam_label=torch.tensor([2, 2, 2, 2], device=DEV))
         m.check_errors()
         got = m(xd, cam_label=torch.tensor([2, 7, 2, 2], device=DEV))        # 7 >= camera_num = 3: clamped to the last row
-    torch.testing.assert_close(got, good, rtol=0, atol=0)
+    torch.testing.assert_close(got, good, rtol=1e-5, atol=1e-5)                  # (split-K fp32 atomics: not bit-identical run to run)
     with pytest.raises(IndexError, match="cam_label"):
         m.check_errors()
     m.check_errors()                                                          # the word was cleared by the raise

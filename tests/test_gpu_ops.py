@@ -131,6 +131,43 @@ def test_gemm_bf16_256_kernel_epilogues(M, N, K, reg_epi):
         lib.demo_gemm_set_pp_epilogue(1)
 
 
+@pytest.mark.parametrize("force,dt", [(0, torch.float32), (1282, torch.bfloat16), (2566, torch.bfloat16)])
+@pytest.mark.parametrize("kind", [ACT_QUICKGELU, ACT_GELU])
+def test_gemm_saved_activation_derivative(force, dt, kind):
+    """pre_out_kind 1 (demo_hip.h): the forward epilogue saves act'(x) instead of the pre-activation x; the backward product then takes
+    act_grad_kind DEMO_ACT_SAVED -- one multiply.  On the generic fp32 kernel and on both MFMA kernels (256^2: forced, incl. a ragged M),
+    against torch autograd of the activation."""
+    from demo2_amd import _lib
+    from demo2_amd._lib import ACT_SAVED
+    lib = _lib.load()
+    M, N, K = (300, 256, 192) if force != 2566 else (2 * 256 + 77, 512, 128)
+    lp = dt == torch.bfloat16
+    a, b, bias = rnd(M, K), rnd(N, K, seed=1, scale=K ** -0.5), rnd(N, seed=2)
+    if lp:
+        a, b = a.bfloat16(), b.bfloat16()
+    x = (a.float() @ b.float().t() + bias).requires_grad_(True)
+    y_ref = act_ref(x, kind)
+    y_ref.sum().backward()
+    lib.demo_gemm_force_tile(force)
+    try:
+        y, dsave = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), act=kind, pre_out_new=True, pre_out_deriv=True)
+        tol = 1e-2 if lp else 1e-5
+        torch.testing.assert_close(y.float().cpu(), y_ref.detach(), rtol=tol, atol=tol)
+        torch.testing.assert_close(dsave.float().cpu(), x.grad, rtol=tol, atol=tol)
+        # backward product on the saved derivative == the same product re-evaluating act' from a saved pre-activation
+        dy, w2t = rnd(M, 64, seed=4), rnd(N, 64, seed=5, scale=0.125)
+        if lp:
+            dy, w2t = dy.bfloat16(), w2t.bfloat16()
+        g_saved = ops.gemm(dy.to(DEV), w2t.to(DEV), act_grad_pre=dsave, act_grad_kind=ACT_SAVED)
+        ref = (dy.float() @ w2t.float().t()) * dsave.float().cpu()
+        torch.testing.assert_close(g_saved.float().cpu(), ref, rtol=tol, atol=tol)
+        _, pre = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), act=kind, pre_out_new=True)
+        g_eval = ops.gemm(dy.to(DEV), w2t.to(DEV), act_grad_pre=pre, act_grad_kind=kind)
+        torch.testing.assert_close(g_saved.float().cpu(), g_eval.float().cpu(), rtol=3e-2 if lp else 1e-5, atol=3e-2 if lp else 1e-5)
+    finally:
+        lib.demo_gemm_force_tile(0)
+
+
 def test_gemm_bf16_row_split_matches_single_launch():
     from demo2_amd import _lib
     lib = _lib.load()
