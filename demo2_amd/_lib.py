@@ -11,7 +11,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdemo_hip.so")
+# DEMO_HIP_LIB: an alternative build of the same library (A/B runs of compile-time variants, e.g. make VARIANT=st2 EXTRA=-DDEMO_STORE_POL=2)
+LIB_PATH = os.environ.get("DEMO_HIP_LIB") or os.path.join(_HERE, "lib", "libdemo_hip.so")
 HEADER_PATH = os.path.join(_HERE, "..", "include", "demo_hip.h")
 
 F32, BF16 = 0, 1
@@ -51,6 +52,7 @@ PROTOTYPES = {
     "demo_gemm_set_split": [C.c_int],
     "demo_gemm_set_pp_epilogue": [C.c_int],
     "demo_gemm_set_pp_min_fill": [C.c_int],
+    "demo_gemm_store_policy": [],
     "demo_cast_f32_bf16": [_P, _P, _L, _P],
     "demo_cast_bf16_f32": [_P, _P, _L, _P],
     "demo_droppath_mask": [_P, _I, _F, _U64, _P, _P],

@@ -156,6 +156,29 @@ __device__ __forceinline__ uint4 f32x8_to_bf16(const float (&v)[8]) {
 // ACT / GK: activation and activation-gradient kinds as COMPILE-TIME constants (-1 = read them from p at run time).  With both
 // as run-time switches every row instance carried QuickGELU and erf-GELU, forward and derivative: 157 KB of code for the
 // 256^2 kernel against a 64-KB instruction cache, and its epilogue ran at instruction-fetch speed.
+// 16-B output store with a compile-time cache policy (-DDEMO_STORE_POL=0 default / 1 nt / 2 sc1 = write-through, line dropped from L2).
+// The output tile is written once and not read again by this kernel, while the weight panel is re-read from L2 by every row panel:
+// plain stores leave 128 KB of dirty lines per tile in the XCD's 4-MB L2.  (A run-time switch put the epilogue's values in scratch.)
+#ifndef DEMO_STORE_POL
+#define DEMO_STORE_POL 0
+#endif
+// base: wave-uniform buffer base (p.C / p.pre_out), off: this lane's BYTE offset into it (< 2^31: the largest output is 304 MB)
+__device__ __forceinline__ void st16(void* base, int64_t off, const u32x4 v) {
+#if DEMO_STORE_POL == 1
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<char*>(base) + off));
+#elif DEMO_STORE_POL == 2
+  // buffer store with aux = 16 (sc1): the compiler counts it like any other store (an inline-asm global_store put the values in scratch)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)off, 0, 16);
+#else
+  *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(base) + off) = v;
+#endif
+}
+__device__ __forceinline__ u32x4 as_u32x4(const uint4 r) { return (u32x4){r.x, r.y, r.z, r.w}; }
+__device__ __forceinline__ u32x4 as_u32x4(float a, float b, float c, float d) {
+  return (u32x4){__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
+}
+
 template <int ACT, int GK>
 __device__ __forceinline__ void epi8_finish(const FArgs& p, const float4 bz0, const float4 bz1, const EpiOps& x, int64_t ci, float (&v)[8]) {
   const int act = ACT >= 0 ? ACT : p.act;
@@ -174,11 +197,10 @@ __device__ __forceinline__ void epi8_finish(const FArgs& p, const float4 bz0, co
       for (int e = 0; e < 8; ++e) s[e] = v[e];
     }
     if (p.dtC == DEMO_F32) {
-      float* q = reinterpret_cast<float*>(p.pre_out) + ci;
-      *reinterpret_cast<float4*>(q) = make_float4(s[0], s[1], s[2], s[3]);
-      *reinterpret_cast<float4*>(q + 4) = make_float4(s[4], s[5], s[6], s[7]);
+      st16(p.pre_out, ci * 4, as_u32x4(s[0], s[1], s[2], s[3]));
+      st16(p.pre_out, ci * 4 + 16, as_u32x4(s[4], s[5], s[6], s[7]));
     } else {
-      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.pre_out) + ci) = f32x8_to_bf16(s);
+      st16(p.pre_out, ci * 2, as_u32x4(f32x8_to_bf16(s)));
     }
   }
   if (act != DEMO_ACT_NONE && !save_deriv) {
@@ -200,10 +222,10 @@ __device__ __forceinline__ void epi8_finish(const FArgs& p, const float4 bz0, co
       v[0] += x.old0.x; v[1] += x.old0.y; v[2] += x.old0.z; v[3] += x.old0.w;
       v[4] += x.old1.x; v[5] += x.old1.y; v[6] += x.old1.z; v[7] += x.old1.w;
     }
-    *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-    *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    st16(p.C, ci * 4, as_u32x4(v[0], v[1], v[2], v[3]));
+    st16(p.C, ci * 4 + 16, as_u32x4(v[4], v[5], v[6], v[7]));
   } else {
-    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + ci) = f32x8_to_bf16(v);
+    st16(p.C, ci * 2, as_u32x4(f32x8_to_bf16(v)));
   }
 }
 // The act'(pre) source (bf16) of ALL of a thread's rows can be requested before the tile is even staged through LDS (4
@@ -850,6 +872,7 @@ int demo_gemm_bf16_eligible(const demo_gemm_desc& d) {
 static int g_force_tile = 0;   // test/bench hook: 128 or 256 forces a configuration, 0 = heuristic
 static int g_pp_reg_epi = 1;   // 256^2 kernel: 1 = register epilogue over permuted weight rows, 0 = LDS-staged row-major epilogue
 static int g_pp_min_eff_pct = 70;
+extern "C" int demo_gemm_store_policy(void) { return DEMO_STORE_POL; }
 extern "C" int demo_gemm_set_pp_min_fill(int pct) { g_pp_min_eff_pct = pct; return 0; }
 void demo_gemm_tn_force(int t);
 // 1280: only pins the weight-gradient (TN) product to its 128^2 form, 1290: to the 256^2 form with fp32 atomics (no two-pass
