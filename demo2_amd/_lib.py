@@ -72,6 +72,7 @@ PROTOTYPES = {
     "demo_optim_step": [_I, _P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _P, _P, _P, _P],
     "demo_batchnorm_fwd": [_P, _P, _P, _P, _P, _I, _F, _F, _P, _I, _P, _P, _I, _I, _I, _I, _I, _L, _L, _P, _P],
     "demo_attention_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "demo_attention_set_variant": [C.c_int],
     "demo_pife_pool_cat": [_P, _I, _P, _I, _I, _I, _P],
     "demo_set_token0": [_P, _I, _P, _L, _I, _I, _I, _P],
     "demo_get_token0": [_P, _I, _P, _L, _I, _I, _I, _P],
@@ -139,6 +140,8 @@ def load():
         lib.demo_gemm_set_pp_epilogue(int(os.environ["DEMO_PP_EPILOGUE"]))      # 0: LDS-staged epilogue of the 256^2 NT kernel
     if "DEMO_PP_MIN_FILL" in os.environ:
         lib.demo_gemm_set_pp_min_fill(int(os.environ["DEMO_PP_MIN_FILL"]))      # 85: the pre-register-epilogue kernel choice
+    if "DEMO_ATTN_VARIANT" in os.environ:
+        lib.demo_attention_set_variant(int(os.environ["DEMO_ATTN_VARIANT"]))    # 0: round-1 attention forward (Q, K, V in LDS)
     if "DEMO_GEMM_SPLIT" in os.environ:
         lib.demo_gemm_set_split(int(os.environ["DEMO_GEMM_SPLIT"]))             # 0: no row split of partial-round products
     _lib = lib

@@ -319,12 +319,19 @@ def attn_ref(qkv, Bn, L, H):
     return o.transpose(1, 2).reshape(Bn * L, D), torch.logsumexp(s, -1).reshape(-1)
 
 
-@pytest.mark.parametrize("Bn,L,H", [(3, 129, 12), (2, 9, 2), (1, 144, 3), (2, 17, 1)])
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
-def test_attention_fwd(Bn, L, H, dt):
+@pytest.mark.parametrize("Bn,L,H", [(3, 129, 12), (2, 9, 2), (1, 144, 3), (2, 17, 1), (2, 145, 2), (1, 160, 1), (5, 128, 4)])
+@pytest.mark.parametrize("dt,variant", [(torch.bfloat16, 1), (torch.bfloat16, 0), (torch.float32, 1)])
+def test_attention_fwd(Bn, L, H, dt, variant):
+    """variant 1 (default): K/V-in-LDS form, 9 key tiles up to L = 144 and 10 up to 160; variant 0: the round-1 kernel."""
+    from demo2_amd import _lib
+    lib = _lib.load()
     qkv = rnd(Bn * L, 3 * H * 64, scale=1.5).to(dt)
     want, lse_want = attn_ref(qkv, Bn, L, H)
-    out, lse = ops.attention_fwd(qkv.to(DEV), Bn, L, H, save_lse=True)
+    lib.demo_attention_set_variant(variant)
+    try:
+        out, lse = ops.attention_fwd(qkv.to(DEV), Bn, L, H, save_lse=True)
+    finally:
+        lib.demo_attention_set_variant(1)
     tol = dict(rtol=1e-4, atol=1e-4) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(out.float().cpu(), want, **tol)
     torch.testing.assert_close(lse.cpu(), lse_want, rtol=1e-3, atol=1e-3)
