@@ -97,6 +97,8 @@ PROTOTYPES = {
     "demo_tokens_grad": [_P, _P, _L, _P, _L, _I, _P, _I, _I, _I, _I, _P],
     "demo_hdm_vbias": [_P, _P, _L, _P, _I, _I, _I, _P],
     "demo_atmoe_gate_softmax": [_P, _P, _P, _I, _I, _I, _P],
+    "demo_atmoe_eval_supported": [_I, _I],
+    "demo_atmoe_eval_fwd": [_P] * 15 + [_L, _L, _F] + [_P] * 5 + [_I, _I, _I, _P],
     "demo_xent_label_smooth": [_P, _L, _P, _I, _I, _F, _F, _P, _P, _L, _P, _P],
     "demo_triplet_soft_margin": [_P, _L, _P, _I, _I, _F, _P, _P, _L, _P, _P],
     "demo_triplet_loss": [_P, _L, _P, _I, _I, _F, _F, _P, _P, _L, _P, _P],

@@ -223,14 +223,22 @@ def hdm_forward(m, tokens: Tensor, ori: Tensor, B: int, training: bool, tape: Op
     sbr_ob = P.stride(*[f + b + ".out_proj.bias" for b in BRANCHES])
     s_tok = P.stride(*[f + b + "_token" for b in BRANCHES])
     o_w, o_b = P.off(f + "r.in_proj_weight"), P.off(f + "r.in_proj_bias")
-    # q[br] = Wq tok + bq  (batch independent)
-    q = torch.empty(7, C, device=dev, dtype=torch.float32)
-    ops.gemm_raw(P.flat, P.flat, q, 1, C, C, C, 1, C, 1, C, a_off=P.off(f + "r_token"), b_off=o_w, bias=P.flat, bias_off=o_b,
-                 batch1=7, sA=(s_tok, 0), sB=(sbr_w, 0), sC=(C, 0), sBias=(sbr_b, 0))
-    # folded keys U[br,h,:] = dh^-0.5 * Wk_h^T q_h   -> rows of a (NC_PAD, C) T matrix, zero padded
-    U = m.workspace("hdm_U", (NC_PAD, C), T, zero=True)
-    ops.gemm_raw(q, P.flat, U, 1, C, 64, C, 1, 1, C, C, b_off=o_w + C * C, alpha=64 ** -0.5, batch1=7, batch2=Hh,
-                 sA=(C, 64), sB=(sbr_w, 64 * C), sC=(Hh * C, C))
+    # q[br] = Wq tok + bq and the folded keys U depend on the WEIGHTS only: at inference they are computed once per parameter
+    # version (m.weight_cache) instead of on every forward; training recomputes them (the weights move every step)
+    cached = m.weight_cache("hdm_qU", T) if tape is None and not training else None
+    if cached is not None:
+        q, U = cached
+    else:
+        # q[br] = Wq tok + bq  (batch independent)
+        q = torch.empty(7, C, device=dev, dtype=torch.float32)
+        ops.gemm_raw(P.flat, P.flat, q, 1, C, C, C, 1, C, 1, C, a_off=P.off(f + "r_token"), b_off=o_w, bias=P.flat, bias_off=o_b,
+                     batch1=7, sA=(s_tok, 0), sB=(sbr_w, 0), sC=(C, 0), sBias=(sbr_b, 0))
+        # folded keys U[br,h,:] = dh^-0.5 * Wk_h^T q_h   -> rows of a (NC_PAD, C) T matrix, zero padded
+        U = m.workspace("hdm_U", (NC_PAD, C), T, zero=True) if tape is not None or training else torch.zeros(NC_PAD, C, device=dev, dtype=T)
+        ops.gemm_raw(q, P.flat, U, 1, C, 64, C, 1, 1, C, C, b_off=o_w + C * C, alpha=64 ** -0.5, batch1=7, batch2=Hh,
+                     sA=(C, 64), sB=(sbr_w, 64 * C), sC=(Hh * C, C))
+        if tape is None and not training:
+            m.weight_cache_put("hdm_qU", T, (q, U))
     S = ops.gemm(tokens, U, out_dtype=torch.float32)                              # (3B*L, NC_PAD)
     p_drop = g.hdm_dropout if training else 0.0
     seed = m.next_seed() if p_drop > 0 else 0
@@ -277,13 +285,19 @@ def dgaf_forward(m, tokens: Tensor, B: int, tape: Optional[Tape] = None) -> Tens
     sv = tape is not None
     s_q = P.stride(d + "rgb_query", d + "nir_query", d + "tir_query")
     o_w, o_b = P.off(d + "attn_pool.in_proj_weight"), P.off(d + "attn_pool.in_proj_bias")
-    # q3[s] = Wq query_s + bq
-    q3 = torch.empty(3, C, device=dev, dtype=torch.float32)
-    ops.gemm_raw(P.flat, P.flat, q3, 3, C, C, s_q, 1, C, 1, C, a_off=P.off(d + "rgb_query"), b_off=o_w, bias=P.flat, bias_off=o_b)
-    # folded keys U[s*nh + h, :] = dh^-0.5 * Wk_h^T q3[s, h]  (zero padded to the MFMA kernel's N granule)
-    U = m.workspace("dgaf_U", (NC_PAD, C), T, zero=True)
-    ops.gemm_raw(q3, P.flat, U, 1, C, dh, C, 1, 1, C, C, b_off=o_w + C * C, alpha=dh ** -0.5, batch1=3, batch2=nh, sA=(C, dh),
-                 sB=(0, dh * C), sC=(nh * C, C))
+    cached = m.weight_cache("dgaf_qU", T) if (not sv and not m.training) else None
+    if cached is not None:
+        q3, U = cached                                  # weights-only quantities, computed once per parameter version at inference
+    else:
+        # q3[s] = Wq query_s + bq
+        q3 = torch.empty(3, C, device=dev, dtype=torch.float32)
+        ops.gemm_raw(P.flat, P.flat, q3, 3, C, C, s_q, 1, C, 1, C, a_off=P.off(d + "rgb_query"), b_off=o_w, bias=P.flat, bias_off=o_b)
+        # folded keys U[s*nh + h, :] = dh^-0.5 * Wk_h^T q3[s, h]  (zero padded to the MFMA kernel's N granule)
+        U = m.workspace("dgaf_U", (NC_PAD, C), T, zero=True) if (sv or m.training) else torch.zeros(NC_PAD, C, device=dev, dtype=T)
+        ops.gemm_raw(q3, P.flat, U, 1, C, dh, C, 1, 1, C, C, b_off=o_w + C * C, alpha=dh ** -0.5, batch1=3, batch2=nh, sA=(C, dh),
+                     sB=(0, dh * C), sC=(nh * C, C))
+        if not sv and not m.training:
+            m.weight_cache_put("dgaf_qU", T, (q3, U))
     S = ops.gemm(tokens, U, out_dtype=torch.float32)                              # (3B*L, NC_PAD)
     pooled, probs = ops.dgaf_attn_pool(S, tokens, B, L, C, nh, NC_PAD, save_probs=sv)
     # per-head value projection o[(b,s), h*dh + e] = Wv_h pooled[b,s,h,:] + bv
@@ -318,6 +332,19 @@ def atmoe_forward(m, feats: Tensor, B: int, training: bool, tape: Optional[Tape]
     P, S = m.ptab, m.stab
     dev = feats.device
     gk = "generalFusion.moe.gating_network.gate."
+    if not training and tape is None and m.fused_atmoe_eval and ops.atmoe_eval_supported(C, H):
+        # inference: the whole module in two launches (csrc/atmoe.hip); BatchNorm = affine map of the running statistics
+        e0 = "generalFusion.moe.experts.0.expertHead.0.mlp."
+        e1 = "generalFusion.moe.experts.0.expertHead.1.mlp."
+        es = P.off(e1 + "0.weight") - P.off(e0 + "0.weight")
+        ss = S.off(e1 + "2.running_mean") - S.off(e0 + "2.running_mean")
+        ws = (m.workspace("atmoe_x2", (B, C), torch.float32), m.workspace("atmoe_k", (B, 7, C), torch.float32),
+              m.workspace("atmoe_y", (B, 7 * C), torch.float32))
+        bn1 = (P.f(gk + "linear_re.2.weight"), P.f(gk + "linear_re.2.bias"), S.f(gk + "linear_re.2.running_mean"),
+               S.f(gk + "linear_re.2.running_var"))
+        return ops.atmoe_eval_fwd(feats, P.f(gk + "linear_re.0.weight"), P.f(gk + "linear_re.0.bias"), bn1, P.f(gk + "q_.weight"),
+                                  P.f(gk + "k_.weight"), P.f(e0 + "0.weight"), P.f(e0 + "0.bias"), P.f(e0 + "2.weight"), P.f(e0 + "2.bias"),
+                                  S.f(e0 + "2.running_mean"), S.f(e0 + "2.running_var"), es, ss, g.bn_eps, B, C, H, ws=ws)
     # (B, 7C) x (7C, C): a skinny product with a long reduction -> runs split-K (linear epilogue), activation applied after
     x1_pre = ops.gemm(feats.view(B, 7 * C), P.f(gk + "linear_re.0.weight"), bias=P.f(gk + "linear_re.0.bias"))
     x1 = ops.act_fwd(x1_pre, ACT_QUICKGELU)

@@ -167,6 +167,8 @@ class DeMo(_Holder):
         self._anchor = None
         self._frozen = None
         self._errors = None
+        self._wcache = {}
+        self.fused_atmoe_eval = os.environ.get("DEMO_FUSED_ATMOE_EVAL", "1") != "0"   # inference: ATMoE in two launches (csrc/atmoe.hip)
         self.grad_sync = None            # set by demo2_amd.dist.GradSync for data-parallel runs
         self.overlap_dw = os.environ.get("DEMO_OVERLAP_DW", "0") == "1"   # opt-in: weight-gradient GEMMs on a side stream (hip_backward.py; measured +1.4 %)
         self._side = None
@@ -427,6 +429,16 @@ class DeMo(_Holder):
             t = (torch.zeros if zero else torch.empty)(*shape, device=self.ptab.flat.device, dtype=dtype)
             self._ws[key] = t
         return t
+
+    def weight_cache(self, name, T):
+        """Quantities that depend on the weights only (HDM / DGAF query projections and folded keys), valid for one parameter version on
+        one device and compute dtype; None when absent or stale."""
+        ver = (self._param_version(), T, self.ptab.flat.device)
+        hit = self._wcache.get(name)
+        return hit[1] if hit is not None and hit[0] == ver else None
+
+    def weight_cache_put(self, name, T, value):
+        self._wcache[name] = ((self._param_version(), T, self.ptab.flat.device), value)
 
     def device_errors(self) -> ops.DeviceErrors:
         """The model's device error word (out-of-range camera ids / labels reported by the kernels, see ops.DeviceErrors)."""

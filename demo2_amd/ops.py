@@ -720,6 +720,33 @@ def atmoe_gate_softmax(q: Tensor, k: Tensor, Bs: int, Cd: int, H: int) -> Tensor
     return gates
 
 
+def atmoe_eval_supported(Cd: int, H: int) -> bool:
+    return bool(_lib.load().demo_atmoe_eval_supported(int(Cd), int(H)))
+
+
+def atmoe_eval_fwd(feats: Tensor, w1: Tensor, b1: Tensor, bn1: tuple, wq: Tensor, wk: Tensor, ew: Tensor, eb: Tensor, ebn_w: Tensor,
+                   ebn_b: Tensor, ebn_mean: Tensor, ebn_var: Tensor, expert_stride: int, stat_stride: int, eps: float, Bs: int, Cd: int,
+                   H: int, ws: Optional[tuple] = None, want_gates: bool = False):
+    """ATMoE in eval mode, two launches (demo_atmoe_eval_fwd): feats (Bs,7,C) fp32 -> moe (Bs,7C) [, gates (Bs,H,7)].  bn1 = (weight,
+    bias, running_mean, running_var) of the gate's BatchNorm; e* tensors START at expert (0,0)'s parameter (views into the flat
+    buffers), consecutive experts `expert_stride` (parameters) / `stat_stride` (running statistics) floats apart."""
+    _req_cuda(feats, w1, b1, wq, wk, ew, eb, ebn_w, ebn_b, ebn_mean, ebn_var, *bn1)
+    assert feats.dtype == torch.float32 and feats.is_contiguous() and feats.numel() == Bs * 7 * Cd
+    dev = feats.device
+    if ws is None:
+        ws = (torch.empty(Bs, Cd, device=dev), torch.empty(Bs, 7, Cd, device=dev), torch.empty(Bs, 7 * Cd, device=dev))
+    x2, kg, y = ws
+    assert x2.numel() >= Bs * Cd and kg.numel() >= Bs * 7 * Cd and y.numel() >= Bs * 7 * Cd
+    moe = torch.empty(Bs, 7 * Cd, device=dev, dtype=torch.float32)
+    gates = torch.empty(Bs, H, 7, device=dev, dtype=torch.float32) if want_gates else None
+    check(_lib.load().demo_atmoe_eval_fwd(feats.data_ptr(), w1.data_ptr(), b1.data_ptr(), bn1[0].data_ptr(), bn1[1].data_ptr(), bn1[2].data_ptr(),
+                                          bn1[3].data_ptr(), wq.data_ptr(), wk.data_ptr(), ew.data_ptr(), eb.data_ptr(), ebn_w.data_ptr(),
+                                          ebn_b.data_ptr(), ebn_mean.data_ptr(), ebn_var.data_ptr(), int(expert_stride), int(stat_stride),
+                                          float(eps), x2.data_ptr(), kg.data_ptr(), y.data_ptr(), moe.data_ptr(), _ptr(gates), Bs, Cd, H, _stream()),
+          "demo_atmoe_eval_fwd")
+    return (moe, gates) if want_gates else moe
+
+
 # ------------------------------------------------------------------------------------------------
 # training losses (value + gradient in one launch)
 # ------------------------------------------------------------------------------------------------

@@ -106,8 +106,12 @@ def test_fused_loss_follows_make_loss_configuration(over):
             cfg.MODEL[k] = v
     torch.manual_seed(5)
     target = (torch.arange(32) // 4).to(DEV)
-    outs = [torch.randn(32, 11, device=DEV, requires_grad=True), torch.randn(32, 896, device=DEV, requires_grad=True),
-            torch.randn(32, 11, device=DEV, requires_grad=True), (0.2 * torch.randn(32, 384, device=DEV)).requires_grad_(True), 0]
+    # features clustered by identity (unit prototypes + noise of two sizes): the margin hinge is active for some anchors only
+    # (drawn on the CPU: the same numbers whatever the device generator does; 16 / 16 anchors on either side of the hinge)
+    protos = torch.randn(8, 384)[torch.arange(32) // 4] * 0.06
+    noise = torch.randn(32, 384) * torch.where(torch.arange(32) % 2 == 0, 0.01, 0.06)[:, None]
+    outs = [torch.randn(32, 11).to(DEV).requires_grad_(True), torch.randn(32, 896).to(DEV).requires_grad_(True),
+            torch.randn(32, 11).to(DEV).requires_grad_(True), (protos + noise).to(DEV).requires_grad_(True), 0]
     ref = total_loss(outs, target, make_loss_fn(cfg))
     ref.backward()
     loss, roots, grads = fused_loss_and_grads(outs, target, cfg)

@@ -65,7 +65,7 @@ def test_embed_tokens_bwd():
     cam = torch.tensor([1, 0, 2, 1, 1])
     for all_tok in (False, True):
         dcls, dpos, dcam = torch.ones(W, device=DEV), torch.ones(np_ + 1, W, device=DEV), torch.ones(3, W, device=DEV)
-        dpatch = ops.embed_tokens_bwd(dpre.to(DEV), cam.to(DEV), 1.5, all_tok, torch.float32, dcls, dpos, dcam, Bn, np_)
+        dpatch = ops.embed_tokens_bwd(dpre.to(DEV), cam.to(DEV), 1.5, all_tok, torch.float32, dcls, dpos, dcam, Bn, np_, n_cam=3)
         d3 = dpre.reshape(Bn, np_ + 1, W)
         torch.testing.assert_close(dpatch.cpu(), d3[:, 1:].reshape(-1, W), rtol=0, atol=0)
         torch.testing.assert_close(dcls.cpu(), 1 + d3[:, 0].sum(0), rtol=1e-5, atol=1e-5)

@@ -72,7 +72,8 @@ def _worker(port, q):
         loss1 = float(ts.step(x, target, cam))
         torch.cuda.synchronize()
         g1 = m.grad_buffer().clone()
-        out.update(loss0=loss0, loss1=loss1, grads_equal=bool(torch.equal(g0, g1)), max_diff=float((g0 - g1).abs().max()),
+        # (two separate backward passes: fp32 atomics make them equal up to summation order, not bit for bit)
+        out.update(loss0=loss0, loss1=loss1, grads_equal=bool(((g0 - g1).norm() / g0.norm()) < 1e-5), max_diff=float((g0 - g1).abs().max()),
                    reduced=sync.reduced_elements, numel=g0.numel(), n_collectives=len(seen), handles_left=len(sync.handles),
                    finite=bool(torch.isfinite(g1).all()), handle_type=seen[0][2] if seen else "")
         # buckets: tail first, then trunk blocks in descending order, then the embedding side
@@ -103,7 +104,7 @@ def test_rccl_calls_of_the_data_parallel_path_execute_on_one_gpu():
     assert "error" not in r, r["error"]
     assert r["backend"] == "nccl"
     assert r["broadcast_unchanged"]
-    assert r["finite"] and r["grads_equal"], r                     # AVG over a one-rank group is the identity, bit for bit
+    assert r["finite"] and r["grads_equal"], r                     # AVG over a one-rank group is the identity
     assert abs(r["loss0"] - r["loss1"]) < 1e-6 * abs(r["loss0"]) + 1e-7
     assert r["reduced"] == r["numel"] and r["handles_left"] == 0    # every gradient element went through a collective; all waited
     assert r["n_collectives"] == 1 + 2 + 2 and r["order_ok"], r     # tail, 4 blocks in buckets of 2, the two embedding-side slices
