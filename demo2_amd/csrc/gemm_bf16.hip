@@ -51,7 +51,11 @@ __device__ __forceinline__ int perm64(int l) {
   const int j = l >> 4, x = l & 15;
   return ((j >> 1) << 5) | ((x >> 2) << 3) | ((j & 1) << 2) | (x & 3);
 }
-template <int ROWS, int NW, bool PERM = false>
+// AUX: cache-policy bits of the LDS-DMA (0 default, 2 = nt: streamed lines are the first to leave L2)
+#ifndef DEMO_A_AUX
+#define DEMO_A_AUX 0      // 256^2 kernel, ACTIVATION operand (read once per row panel; -DDEMO_A_AUX=2 is an A/B variant of the library)
+#endif
+template <int ROWS, int NW, bool PERM = false, int AUX = 0>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int64_t ld, int row0, int row_max, int k0,
                                            char* lds_tile, int wave, int lane) {
   constexpr int NSEG = ROWS / 8;
@@ -63,7 +67,7 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int64_t
     int gr = row0 + (PERM ? (r & ~63) + perm64(r & 63) : r);
     gr = gr < row_max ? gr : row_max - 1;     // clamp: rows past the edge are loaded but never stored
     const bf16_t* src = G + (int64_t)gr * ld + k0 + c * 8;
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(lds_tile + seg * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(lds_tile + seg * 1024), 16, 0, AUX);
   }
 }
 
@@ -740,10 +744,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
   // (De-phasing the first round of workgroups with s_sleep, so that CUs do not reach their store-heavy epilogues together,
   // was tried -- 2/4/8 phase groups, 7..17 us apart -- and measured 2..6 % slower on the training step.)
   // first K-tiles: A(0) -> A slot 0, B(0) -> B slot 1, A(1) -> A slot 1
-  stage_tile<BM, NW>(A, p.lda, m0, p.M, 0, smem, wave, lane);
+  stage_tile<BM, NW, false, DEMO_A_AUX>(A, p.lda, m0, p.M, 0, smem, wave, lane);
   stage_tile<BN, NW, REG_EPI>(B, p.ldb, n0, p.N, 0, smem_b + B_BYTES, wave, lane);
   if (nk > 1) {
-    stage_tile<BM, NW>(A, p.lda, m0, p.M, BK, smem + A_BYTES, wave, lane);
+    stage_tile<BM, NW, false, DEMO_A_AUX>(A, p.lda, m0, p.M, BK, smem + A_BYTES, wave, lane);
     wait_vmcnt<4>();                                // K-tile 0 landed; A(1), the 4 youngest loads, may still fly
   } else {
     wait_vmcnt<0>();
@@ -783,7 +787,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
     // ---- P2
     lds_read2(b1f[0], lb + 4096 + foff0);
     lds_read2(b1f[1], lb + 4096 + foff1);
-    if (has2) stage_tile<BM, NW>(A, p.lda, m0, p.M, (t + 2) * BK, smem + sa2 * A_BYTES, wave, lane);
+    if (has2) stage_tile<BM, NW, false, DEMO_A_AUX>(A, p.lda, m0, p.M, (t + 2) * BK, smem + sa2 * A_BYTES, wave, lane);
     PP_MFMA(af, b1f, 0, 2);
     // ---- P3
     lds_read4(af[0], la + 8192 + foff0);

@@ -461,3 +461,71 @@ def test_atmoe_gate_softmax(Bs, Cd, H):
     want = (torch.einsum("bhd,bjhd->bhj", q.reshape(Bs, H, d), k.reshape(Bs, 7, H, d)) * d ** -0.5).softmax(-1)
     got = ops.atmoe_gate_softmax(q.to(DEV), k.to(DEV), Bs, Cd, H)
     torch.testing.assert_close(got.cpu(), want, rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ fusion module vs the reference's golden outputs
+@pytest.mark.parametrize("name,C,H", [("fusion_c128_h4", 128, 4), ("fusion_c64_h2", 64, 2)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_general_fusion_eval_against_reference_golden(golden, name, C, H, fused):
+    """GeneralFusion (HDM + ATMoE) at inference on the HIP schedule against the outputs of the reference's OWN module
+    (tests/golden/fusion_*.npz, oracle/gen_golden.py: gen_fusion) -- HDM features, gate tensor and the (B, 7C) mixture, B in {1, 2, 4} --
+    with ATMoE in its fused two-launch form (csrc/atmoe.hip) and in the multi-launch form training uses; the weight-only quantities
+    of HDM come from the per-parameter-version cache on the second and third batch."""
+    from demo2_amd.modeling import hip_forward as HF, make_model
+    from util import small_cfg
+    g = golden(name)
+    cfg = small_cfg("clip", head=H, TRUNK_OUT_DIM=C)
+    torch.manual_seed(0)
+    m = make_model(cfg, 11, 3, 0)
+    missing = m.load_state_dict({"generalFusion." + k: v for k, v in g["sd"].items()}, strict=False)
+    assert not [k for k in missing.unexpected_keys] and not [k for k in missing.missing_keys if k.startswith("generalFusion.")]
+    m = m.to(DEV).eval().set_compute_dtype(torch.float32)
+    m.fused_atmoe_eval = fused
+    if fused:
+        assert ops.atmoe_eval_supported(C, H)
+    for B in (1, 2, 4):
+        e = g[f"eval_b{B}"]
+        L = e["in0"].shape[1] + 1
+        # token streams as the trunk leaves them: (3B*L, C), row 0 of every image = the (PIFE) global, rows 1.. = the patch tokens
+        tokens = torch.cat([torch.cat([e[f"in{3 + i}"][:, None, :], e[f"in{i}"]], 1) for i in range(3)], 0).reshape(3 * B * L, C)
+        ori = torch.cat([e[f"in{3 + i}"] for i in range(3)], 1)
+        m.geom.n_patches = L - 1
+        feats = HF.hdm_forward(m, tokens.to(DEV), ori.to(DEV), B, False)
+        for i in range(7):
+            torch.testing.assert_close(feats[:, i].cpu(), e[f"hdm{i}"].reshape(B, C), rtol=2e-4, atol=2e-5)
+        moe = HF.atmoe_forward(m, feats, B, False)
+        torch.testing.assert_close(moe.cpu(), e["out"].reshape(B, 7 * C), rtol=2e-4, atol=2e-5)
+        if fused:                                               # the gate tensor itself (AttnMOE.py:61-68), from the fused kernels
+            P, S, gk = m.ptab, m.stab, "generalFusion.moe.gating_network.gate."
+            e0, e1 = "generalFusion.moe.experts.0.expertHead.0.mlp.", "generalFusion.moe.experts.0.expertHead.1.mlp."
+            bn1 = (P.f(gk + "linear_re.2.weight"), P.f(gk + "linear_re.2.bias"), S.f(gk + "linear_re.2.running_mean"), S.f(gk + "linear_re.2.running_var"))
+            _, gates = ops.atmoe_eval_fwd(feats, P.f(gk + "linear_re.0.weight"), P.f(gk + "linear_re.0.bias"), bn1, P.f(gk + "q_.weight"),
+                                          P.f(gk + "k_.weight"), P.f(e0 + "0.weight"), P.f(e0 + "0.bias"), P.f(e0 + "2.weight"), P.f(e0 + "2.bias"),
+                                          S.f(e0 + "2.running_mean"), S.f(e0 + "2.running_var"), P.off(e1 + "0.weight") - P.off(e0 + "0.weight"),
+                                          S.off(e1 + "2.running_mean") - S.off(e0 + "2.running_mean"), 1e-5, B, C, H, want_gates=True)
+            torch.testing.assert_close(gates.cpu(), e["gate"].reshape(B, H, 7), rtol=2e-4, atol=2e-5)
+    assert m.weight_cache("hdm_qU", torch.float32) is not None
+    # a parameter update invalidates the cache
+    with torch.no_grad():
+        m.generalFusion.r_token.add_(0.5)
+    assert m.weight_cache("hdm_qU", torch.float32) is None
+
+
+@pytest.mark.parametrize("B,C,H", [(1, 512, 4), (37, 512, 8), (130, 768, 12)])
+def test_atmoe_eval_fused_equals_multi_launch_at_full_width(B, C, H):
+    """Configs A / B / V widths (d = 128 / 64 / 64), ragged sample blocks: the two-launch form against the multi-launch schedule."""
+    from demo2_amd.modeling import hip_forward as HF, make_model
+    from util import make_cfg
+    kw = dict(HEAD=H) if C == 512 else dict(HEAD=H, TRANSFORMER_TYPE="vit_base_patch16_224", SIE_COE=3.0, TRUNK_WIDTH=768)
+    cfg = make_cfg("RGBNT201", TRUNK_LAYERS=1, **kw)
+    torch.manual_seed(0)
+    m = make_model(cfg, 11, 3, 0)
+    sd = O.init_state_dict(__import__("util").spec_of(m), seed=3)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    feats = rnd(B, 7, C, seed=B).to(DEV)
+    m.fused_atmoe_eval = True
+    a = HF.atmoe_forward(m, feats, B, False)
+    m.fused_atmoe_eval = False
+    b = HF.atmoe_forward(m, feats, B, False)
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of whole training steps on ONE box: saved activation derivative on/off, epilogue store policy variants (compile-time builds selected
-# with DEMO_HIP_LIB), then the HBM-traffic counter passes for the default and the sc1 build.  Usage (on the GPU box): bash tools/ab_store.sh
+# with DEMO_HIP_LIB).  Usage (on the GPU box): bash tools/ab_store.sh [noderiv] [attn0] [<library variant> ...]
 set -o pipefail
 cd "$(dirname "$0")/.."
 O=gpurun_out/ab
@@ -16,7 +16,11 @@ print("$name", d["ms_per_step"], "ms", d["value"], "img/s  dominant", r["achieve
 P
 }
 run base0 DEMO_X=0
-run noderiv DEMO_SAVE_ACT_DERIV=0
-run st2 DEMO_HIP_LIB=$L/libdemo_hip_st2.so
-run st1 DEMO_HIP_LIB=$L/libdemo_hip_st1.so
+for v in "$@"; do
+  case $v in
+    noderiv) run noderiv DEMO_SAVE_ACT_DERIV=0 ;;
+    attn0) run attn0 DEMO_ATTN_VARIANT=0 ;;
+    *) run $v DEMO_HIP_LIB=$L/libdemo_hip_$v.so ;;
+  esac
+done
 run base1 DEMO_X=0
