@@ -167,8 +167,15 @@ __device__ __forceinline__ uint4 f32x8_to_bf16(const float (&v)[8]) {
 #define DEMO_STORE_POL 0
 #endif
 // base: wave-uniform buffer base (p.C / p.pre_out), off: this lane's BYTE offset into it (< 2^31: the largest output is 304 MB)
+// DEMO_EPI_ABLATE (measurement builds only, never the product): 1 = the epilogue computes everything but stores nothing, 2 = no epilogue
+// at all (the accumulators are kept live so that the main loop is not optimised away): cost-structure ablations, guide rule 17
+#ifndef DEMO_EPI_ABLATE
+#define DEMO_EPI_ABLATE 0
+#endif
 __device__ __forceinline__ void st16(void* base, int64_t off, const u32x4 v) {
-#if DEMO_STORE_POL == 1
+#if DEMO_EPI_ABLATE == 1
+  asm volatile("" ::"v"(v), "v"(off));
+#elif DEMO_STORE_POL == 1
   __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<char*>(base) + off));
 #elif DEMO_STORE_POL == 2
   // buffer store with aux = 16 (sc1): the compiler counts it like any other store (an inline-asm global_store put the values in scratch)
@@ -811,7 +818,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
   const int g4 = lane >> 4;
   if constexpr (REG_EPI) {
     // register epilogue (see pp_epi_k): no LDS image, no barrier
+#if DEMO_EPI_ABLATE == 2
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+#else
     pp_epi(p, acc, m0 + wr * 128 + frow, n0 + wc * 64 + g4 * 8, coff, bias);
+#endif
     return;
   }
   float* ct = reinterpret_cast<float*>(smem);
