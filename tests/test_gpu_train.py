@@ -174,9 +174,14 @@ def test_full_depth_bf16_gradients_against_fp32_oracle(B):
     print(f"\nbf16 mode vs fp32 oracle, config A, 12 blocks, B={B}: whole gradient rel err {whole_rel:.4f}, cosine {whole_cos:.6f}; "
           f"{len(live)}/{len(names)} live parameters: rel err median {rv[len(rv) // 2]:.4f} p90 {rv[int(0.9 * len(rv))]:.4f} max {rv[-1]:.4f}; "
           f"min cosine {worst_cos[0][1]:.5f}\n  worst rel: {worst_rel}\n  worst cos: {worst_cos}")
-    lim = dict(whole_rel=0.20, whole_cos=0.98, med=0.20, p90=0.30) if B == 4 else dict(whole_rel=0.10, whole_cos=0.995, med=0.10, p90=0.18)
+    # Measured on MI355X (round 2):  B = 16: whole gradient 2.9 % / cosine 0.99958, per parameter median 3.1 %, p90 4.2 %, max 14.4 %
+    # (an expert bias), min cosine 0.9927.   B = 4: whole 12.7 % / 0.9924, median 12.2 %, p90 17.0 % -- uniform over the trunk too, i.e.
+    # it enters at the loss (4-sample BatchNorm statistics and batch-hard mining among 4), not in the bf16 products.
+    lim = (dict(whole_rel=0.18, whole_cos=0.985, med=0.18, p90=0.25, mx=1.5, cos=0.5) if B == 4 else
+           dict(whole_rel=0.045, whole_cos=0.999, med=0.045, p90=0.065, mx=0.25, cos=0.985))
     assert whole_rel < lim["whole_rel"] and whole_cos > lim["whole_cos"], (whole_rel, whole_cos)
     assert rv[len(rv) // 2] < lim["med"] and rv[int(0.9 * len(rv))] < lim["p90"], (rv[len(rv) // 2], rv[int(0.9 * len(rv))])
+    assert rv[-1] < lim["mx"] and worst_cos[0][1] > lim["cos"], (worst_rel, worst_cos)
 
 
 FULL = {
