@@ -859,6 +859,123 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
   }
 }
 
+// ---- 256 x 128 "twin" kernel: TWO workgroups per CU -----------------------------------------------------------------------------
+// Same wave tile as the 256^2 kernel (128 x 64 per wave: 8 x 4 MFMA tiles, 128 accumulator registers, the register epilogue pp_epi
+// with its permuted weight rows), but a workgroup is 4 waves (2 x 2) on a 256 x 128 output tile with a 32-deep K-step, so its LDS
+// ring is 3 stages x 24 KB = 72 KB and TWO workgroups share a CU (one wave of each per SIMD, 256 VGPRs apiece).  What that buys: the
+// 256^2 kernel's epilogue -- 128..256 KB of output stores per tile, ~5.5 us per round of tiles at HBM write speed, 12 us with
+// QuickGELU and two outputs -- overlaps with nothing at one workgroup per CU (tools/gemm_cost.py: N = 3072, K = 768 runs at 1195
+// TFLOP/s without its epilogue, 932 with a bias-only one, 725 with the fc1 one); here one workgroup's epilogue and prologue run
+// under the other's main loop.  What it costs: 85 instead of 128 flop per byte moved L2 -> LDS, and a barrier every 32 MFMAs.
+//   LDS rows are 64 B (32 bf16): a 16-row fragment tile is 1 KB = ONE LDS-DMA piece.  Conflict-free ds_read_b128 needs the 16-B chunk
+//   index XOR-ed with S[(row >> 2) & 3], S = {0, 2, 3, 1} (the four 16-lane groups of a b128 read then cover 16 distinct 16-B slots
+//   of the 256-B bank row); as everywhere the swizzle is applied to the per-lane SOURCE address of the DMA and to the read address.
+constexpr int TW_BK = 32, TW_BM = 256, TW_BN = 128, TW_STAGE = (TW_BM + TW_BN) * TW_BK * 2, TW_NS = 3;
+__device__ __forceinline__ int tw_swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }      // S = {0, 2, 3, 1}
+
+template <int ROWS, bool PERM>
+__device__ __forceinline__ void tw_stage(const bf16_t* __restrict__ G, int64_t ld, int row0, int row_max, int k0, char* lds_tile, int wave,
+                                         int lane) {
+  constexpr int NP = ROWS / 16;                    // 1-KB pieces (16 rows x 64 B), dealt to the 4 waves
+#pragma unroll
+  for (int j = 0; j < NP / 4; ++j) {
+    const int piece = j * 4 + wave;
+    const int r = piece * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ tw_swz(r);
+    int gr = row0 + (PERM ? (r & ~63) + perm64(r & 63) : r);
+    gr = gr < row_max ? gr : row_max - 1;
+    const bf16_t* src = G + (int64_t)gr * ld + k0 + c * 8;
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(lds_tile + piece * 1024), 16, 0, 0);
+  }
+}
+// four ds_read_b128 of fragment tiles 0..3 (1024 B apart) from one base; NOT waited for here
+__device__ __forceinline__ void tw_read4(bf16x8 (&f)[4], unsigned base) {
+  asm volatile("ds_read_b128 %0, %4\n\t"
+               "ds_read_b128 %1, %4 offset:1024\n\t"
+               "ds_read_b128 %2, %4 offset:2048\n\t"
+               "ds_read_b128 %3, %4 offset:3072"
+               : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3])
+               : "v"(base)
+               : "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_twin_kernel(const FArgs p) {
+  __shared__ __attribute__((aligned(1024))) char smem[TW_NS * TW_STAGE];
+  constexpr int A_BYTES = TW_BM * TW_BK * 2;                       // 16 KB; B follows A inside a stage
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  // XCD-aware tile id, groups of row panels walked against all weight panels (as in the 256^2 kernel)
+  const int nwg = p.ntm * p.ntn;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+  const int tid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  const int group_m = p.group_m;
+  const int per_group = group_m * p.ntn;
+  const int grp = tid / per_group, in_grp = tid - grp * per_group;
+  const int gm0 = grp * group_m;
+  const int gsz = (p.ntm - gm0) < group_m ? (p.ntm - gm0) : group_m;
+  const int m0 = (gm0 + in_grp % gsz) * TW_BM, n0 = (in_grp / gsz) * TW_BN;
+  const int z = blockIdx.y;
+  const bf16_t* A = p.A + z * p.sA;
+  const bf16_t* B = p.B + z * p.sB;
+
+  const int frow = lane & 15, g4 = lane >> 4;
+  const int foff = frow * 64 + ((g4 ^ tw_swz(frow)) << 4);        // this lane's 16 B inside a 16-row fragment tile
+  const int nk = p.K / TW_BK;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // stages 0 and 1 (6 LDS-DMA pieces per wave and stage: 4 of A, 2 of B)
+  tw_stage<TW_BM, false>(A, p.lda, m0, p.M, 0, smem, wave, lane);
+  tw_stage<TW_BN, true>(B, p.ldb, n0, p.N, 0, smem + A_BYTES, wave, lane);
+  if (nk > 1) {
+    tw_stage<TW_BM, false>(A, p.lda, m0, p.M, TW_BK, smem + TW_STAGE, wave, lane);
+    tw_stage<TW_BN, true>(B, p.ldb, n0, p.N, TW_BK, smem + TW_STAGE + A_BYTES, wave, lane);
+  }
+  int slot = 0;
+  for (int t = 0; t < nk; ++t) {
+    if (t + 1 < nk) wait_vmcnt<6>();               // stage t landed; stage t+1 (the 6 youngest) may still fly
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                  // every wave's part of stage t is in LDS; everyone is done reading stage t-1
+    if (t + 2 < nk) {
+      char* nxt = smem + (slot == 0 ? 2 : slot - 1) * TW_STAGE;     // slot of stage t-1 == slot of stage t+2
+      tw_stage<TW_BM, false>(A, p.lda, m0, p.M, (t + 2) * TW_BK, nxt, wave, lane);
+      tw_stage<TW_BN, true>(B, p.ldb, n0, p.N, (t + 2) * TW_BK, nxt + A_BYTES, wave, lane);
+    }
+    const unsigned la = lds_off(smem + slot * TW_STAGE + wr * (128 * 64) + foff);
+    const unsigned lb = lds_off(smem + slot * TW_STAGE + A_BYTES + wc * (64 * 64) + foff);
+    slot = slot == 2 ? 0 : slot + 1;
+    bf16x8 bf[4], a0[4], a1[4];
+    tw_read4(bf, lb);
+    tw_read4(a0, la);
+    tw_read4(a1, la + 4096);
+    asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], a0[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], a1[i], acc[4 + i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const int64_t coff = z * p.sC;
+  const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
+  pp_epi(p, acc, m0 + wr * 128 + frow, n0 + wc * 64 + g4 * 8, coff, bias);
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -1012,6 +1129,12 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
         hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<true>, dim3((unsigned)(p.ntm * p.ntn), (unsigned)nb), dim3(512), 0, s, p);
       else
         hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<false>, dim3((unsigned)(p.ntm * p.ntn), (unsigned)nb), dim3(512), 0, s, p);
+      break;
+    case 2576:                                       // 256 x 128 twin kernel (two workgroups per CU)
+      p.ntm = (int)cdiv64(d.M, 256);
+      p.ntn = d.N / 128;
+      p.group_m = 64 / p.ntn < 1 ? 1 : (64 / p.ntn > 8 ? 8 : 64 / p.ntn);
+      hipLaunchKernelGGL(gemm_bf16_nt_twin_kernel, dim3((unsigned)(p.ntm * p.ntn), (unsigned)nb), dim3(256), 0, s, p);
       break;
     case 1292: LAUNCH_RS(128, 128, 2, 2); break;
     case 2592: LAUNCH_RS(256, 128, 4, 2); break;

@@ -64,7 +64,9 @@ cases = [
     ("proj fwd  bias+fp32 residual        N=768  K=768 ", 2.0 * M * W * W, lambda: ops.gemm(x, wp, bias=b2, residual=res32, out=o32)),
     ("proj bwd  plain                     N=768  K=768 ", 2.0 * M * W * W, lambda: ops.gemm(x, wp, out=o16s)),
 ]
-lib.demo_gemm_force_tile(2566)
+TILE = int(os.environ.get("DEMO_FORCE_TILE", "2566"))
+tag = f"{tag}:{TILE}"
+lib.demo_gemm_force_tile(TILE)
 lib.demo_gemm_set_split(0)
 try:
     for name, fl, fn in cases:
