@@ -38,6 +38,7 @@ struct FArgs {
   float alpha;
   int ntm, ntn;
   int group_m;                 // 256^2 kernel: row panels per tile-order group
+  int dephase;                 // 256^2 kernel, tuning hook: first-round workgroups start ((id >> 3) & 3) * dephase * 64 clocks late
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -749,7 +750,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // (De-phasing the first round of workgroups with s_sleep, so that CUs do not reach their store-heavy epilogues together,
-  // was tried -- 2/4/8 phase groups, 7..17 us apart -- and measured 2..6 % slower on the training step.)
+  // was tried in round 1 -- 2/4/8 phase groups, 7..17 us apart -- and measured 2..6 % slower on the training step.  Round 2
+  // re-measured it with small offsets behind a tuning hook (demo_gemm_set_dephase), see DESIGN.md.)
+  if (p.dephase > 0 && bid < 256) {
+    const int n = ((bid >> 3) & 3) * p.dephase;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+  }
   // first K-tiles: A(0) -> A slot 0, B(0) -> B slot 1, A(1) -> A slot 1
   stage_tile<BM, NW, false, DEMO_A_AUX>(A, p.lda, m0, p.M, 0, smem, wave, lane);
   stage_tile<BN, NW, REG_EPI>(B, p.ldb, n0, p.N, 0, smem_b + B_BYTES, wave, lane);
@@ -1007,6 +1013,8 @@ int demo_gemm_bf16_eligible(const demo_gemm_desc& d) {
 static int g_force_tile = 0;   // test/bench hook: 128 or 256 forces a configuration, 0 = heuristic
 static int g_pp_reg_epi = 1;   // 256^2 kernel: 1 = register epilogue over permuted weight rows, 0 = LDS-staged row-major epilogue
 static int g_pp_min_eff_pct = 70;
+static int g_dephase = 0;
+extern "C" int demo_gemm_set_dephase(int units) { g_dephase = units < 0 ? 0 : units; return 0; }
 extern "C" int demo_gemm_store_policy(void) { return DEMO_STORE_POL; }
 extern "C" int demo_gemm_set_pp_min_fill(int pct) { g_pp_min_eff_pct = pct; return 0; }
 void demo_gemm_tn_force(int t);
@@ -1092,6 +1100,7 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
   p.pre = d.act_grad_pre;
   p.pre_out = d.pre_out;
   p.pre_out_kind = d.pre_out ? d.pre_out_kind : 0;
+  p.dephase = g_dephase;
   p.M = d.M; p.N = d.N; p.K = d.K;
   p.lda = d.a_rs; p.ldb = d.b_rs; p.ldc = d.c_rs;
   const bool lvl1 = d.batch1 != 1;

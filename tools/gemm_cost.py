@@ -68,6 +68,8 @@ TILE = int(os.environ.get("DEMO_FORCE_TILE", "2566"))
 tag = f"{tag}:{TILE}"
 lib.demo_gemm_force_tile(TILE)
 lib.demo_gemm_set_split(0)
+if "DEMO_GEMM_DEPHASE" in os.environ:
+    tag += ":dephase" + os.environ["DEMO_GEMM_DEPHASE"]
 try:
     for name, fl, fn in cases:
         t = timeit(fn)
