@@ -81,9 +81,9 @@ def gemm_roofline(model, step_fn):
         nb = d.batch1 * d.batch2
         szc = 4 if d.dtC == _lib.F32 else 2
         nbytes = nb * (2 * d.M * d.K + 2 * d.N * d.K + d.M * d.N * szc * (2 if d.pre_out else 1)
-                       + (d.M * d.N * 4 if d.residual else 0) + (d.M * d.N * 4 if d.accumulate else 0)
+                       + (d.M * d.N * (2 if d.dtRes == _lib.BF16 else 4) if d.residual else 0) + (d.M * d.N * 4 if d.accumulate else 0)
                        + (d.M * d.N * (4 if d.dtPre == _lib.F32 else 2) if d.act_grad_pre else 0))
-        epi = "+".join(t for t, on in (("bias", d.bias), ("act", d.act), ("save_pre", d.pre_out), ("fp32_residual", d.residual),
+        epi = "+".join(t for t, on in (("bias", d.bias), ("act", d.act), ("save_pre", d.pre_out), ("bf16_residual" if d.dtRes == _lib.BF16 else "fp32_residual", d.residual),
                                        ("act_grad", d.act_grad_pre), ("accumulate", d.accumulate)) if on) or "plain"
         recs[path].append((e0, e1, 2.0 * d.M * d.N * d.K * nb, nbytes, (d.M, d.N, d.K, epi)))
         return rc
@@ -105,7 +105,7 @@ def gemm_roofline(model, step_fn):
             d2.A = d.A + m1 * d.a_rs * 2
             d2.C = d.C + m1 * d.c_rs * szc
             if d.residual:
-                d2.residual = d.residual + m1 * d.c_rs * 4
+                d2.residual = d.residual + m1 * d.c_rs * (2 if d.dtRes == _lib.BF16 else 4)
             if d.act_grad_pre:
                 d2.act_grad_pre = d.act_grad_pre + m1 * d.c_rs * szp
             if d.pre_out:

@@ -27,10 +27,11 @@ struct FArgs {
   const bf16_t* B;
   void* C;
   const float* bias;
-  const float* residual;
+  const void* residual;        // fp32 (dtRes 0) or bf16 (dtRes DEMO_BF16), indexed like C
   const void* pre;
   void* pre_out;
   int pre_out_kind;            // 0: pre-activation, 1: act'(pre-activation)
+  int dtRes;
   int M, N, K;
   int64_t lda, ldb, ldc;
   int64_t sA, sB, sC, sBias;   // batch strides (single level)
@@ -119,7 +120,8 @@ __device__ __forceinline__ void epi4(const FArgs& p, const float4 b4, int64_t co
     v[2] *= act_grad(pr.z, p.act_grad_kind); v[3] *= act_grad(pr.w, p.act_grad_kind);
   }
   if (p.residual) {
-    const float4 r4 = *reinterpret_cast<const float4*>(p.residual + ci);
+    const float4 r4 = p.dtRes == DEMO_BF16 ? io<bf16_t>::ld4(reinterpret_cast<const bf16_t*>(p.residual) + ci)
+                                           : *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.residual) + ci);
     v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
   }
   if (p.dtC == DEMO_F32) {
@@ -296,10 +298,18 @@ __device__ __forceinline__ void epi_rows_k(const FArgs& p, const float* __restri
       }
     }
     if (p.residual) {
+      if (p.dtRes == DEMO_BF16) {
+        uint4 rraw[G];
 #pragma unroll
-      for (int u = 0; u < G; ++u) {
-        x[u].res0 = *reinterpret_cast<const float4*>(p.residual + ci[u]);
-        x[u].res1 = *reinterpret_cast<const float4*>(p.residual + ci[u] + 4);
+        for (int u = 0; u < G; ++u) rraw[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.residual) + ci[u]);
+#pragma unroll
+        for (int u = 0; u < G; ++u) bf16x8_to_f32(rraw[u], x[u].res0, x[u].res1);
+      } else {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          x[u].res0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.residual) + ci[u]);
+          x[u].res1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.residual) + ci[u] + 4);
+        }
       }
     }
     if (p.accumulate && p.dtC == DEMO_F32) {
@@ -347,7 +357,7 @@ __device__ __forceinline__ void epi_rows(const FArgs& p, const float* __restrict
 // independently (the LDS-staged form wrote and re-read 256 KB of LDS per tile behind four workgroup barriers), and four lanes of
 // a store instruction cover 64 contiguous bytes of a row.  Rows are finished G row tiles at a time, every global operand of the
 // group requested first.
-// LOADS: which global operands besides the bias the epilogue reads, as a compile-time mask (1 residual, 2 act'(pre) source in bf16,
+// LOADS: which global operands besides the bias the epilogue reads, as a compile-time mask (1 fp32 residual, 5 = 1 | 4 bf16 residual, 2 act'(pre) source in bf16,
 // 0 none) or -1 = decided at run time (any combination, G = 1: every unit then budgets all 24 operand registers).
 template <int G, int ACT, int GK, int LOADS>
 __device__ __forceinline__ void pp_epi_k(const FArgs& p, const f32x4 (&acc)[8][4], int mrow, int ncol, int64_t coff, const float* bias) {
@@ -355,6 +365,7 @@ __device__ __forceinline__ void pp_epi_k(const FArgs& p, const f32x4 (&acc)[8][4
   const bool has_res = LOADS >= 0 ? (LOADS & 1) != 0 : p.residual != nullptr;
   const bool has_old = LOADS >= 0 ? false : (p.accumulate && p.dtC == DEMO_F32);
   const bool pre_bf16 = LOADS >= 0 ? true : p.dtPre == DEMO_BF16;
+  const bool res_bf16 = LOADS >= 0 ? (LOADS & 4) != 0 : p.dtRes == DEMO_BF16;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 bz[2][2] = {{z4, z4}, {z4, z4}};
   if (bias) {
@@ -402,13 +413,25 @@ __device__ __forceinline__ void pp_epi_k(const FArgs& p, const f32x4 (&acc)[8][4
       }
     }
     if (has_res) {
+      if (res_bf16) {
+        uint4 rraw[G][2];
 #pragma unroll
-      for (int u = 0; u < G; ++u)
+        for (int u = 0; u < G; ++u)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          x[u][h].res0 = *reinterpret_cast<const float4*>(p.residual + ci[u][h]);
-          x[u][h].res1 = *reinterpret_cast<const float4*>(p.residual + ci[u][h] + 4);
-        }
+          for (int h = 0; h < 2; ++h) rraw[u][h] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.residual) + ci[u][h]);
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) bf16x8_to_f32(rraw[u][h], x[u][h].res0, x[u][h].res1);
+      } else {
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            x[u][h].res0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.residual) + ci[u][h]);
+            x[u][h].res1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.residual) + ci[u][h] + 4);
+          }
+      }
     }
     if (has_old) {
 #pragma unroll
@@ -439,8 +462,9 @@ __device__ __forceinline__ void pp_epi(const FArgs& p, const f32x4 (&acc)[8][4],
     else if (p.act == DEMO_ACT_QUICKGELU) pp_epi_k<1, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE, 0>(p, acc, mrow, ncol, coff, bias);
     else if (p.act == DEMO_ACT_GELU) pp_epi_k<1, DEMO_ACT_GELU, DEMO_ACT_NONE, 0>(p, acc, mrow, ncol, coff, bias);
     else pp_epi_k<1, -1, -1, -1>(p, acc, mrow, ncol, coff, bias);
-  } else if (p.residual && !p.pre && !old && p.act == DEMO_ACT_NONE) {       // proj / fc2 forward: + fp32 residual
-    pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_NONE, 1>(p, acc, mrow, ncol, coff, bias);
+  } else if (p.residual && !p.pre && !old && p.act == DEMO_ACT_NONE) {       // proj / fc2 forward: + residual (fp32, or the bf16 stream)
+    if (p.dtRes == DEMO_BF16) pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_NONE, 5>(p, acc, mrow, ncol, coff, bias);
+    else pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_NONE, 1>(p, acc, mrow, ncol, coff, bias);
   } else if (p.pre && p.dtPre == DEMO_BF16 && !p.residual && !old && p.act == DEMO_ACT_NONE && gk == DEMO_ACT_QUICKGELU) {
     pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_QUICKGELU, 2>(p, acc, mrow, ncol, coff, bias);   // MLP backward: (dY W2^T) * act'(pre)
   } else if (p.pre && p.dtPre == DEMO_BF16 && !p.residual && !old && p.act == DEMO_ACT_NONE && gk == DEMO_ACT_GELU) {
@@ -995,6 +1019,7 @@ int demo_gemm_bf16_eligible(const demo_gemm_desc& d) {
   if (!al16(d.A) || !al16(d.B) || !al16(d.C)) return 0;
   if (d.bias && !al16(d.bias)) return 0;
   if (d.residual && !al16(d.residual)) return 0;
+  if (d.residual && d.dtRes == DEMO_BF16 && d.c_rs % 8) return 0;
   if (d.act_grad_pre && !al16(d.act_grad_pre)) return 0;
   if (d.pre_out && !al16(d.pre_out)) return 0;
   if (d.accumulate && d.dtC != DEMO_F32) return 0;
@@ -1084,7 +1109,7 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
     const int64_t szC = d.dtC == DEMO_F32 ? 4 : 2, szP = d.dtPre == DEMO_F32 ? 4 : 2;
     b.A = (const char*)d.A + (int64_t)m1 * d.a_rs * 2;
     b.C = (char*)d.C + (int64_t)m1 * d.c_rs * szC;
-    if (d.residual) b.residual = d.residual + (int64_t)m1 * d.c_rs;
+    if (d.residual) b.residual = (const char*)d.residual + (int64_t)m1 * d.c_rs * (d.dtRes == DEMO_BF16 ? 2 : 4);
     if (d.act_grad_pre) b.act_grad_pre = (const char*)d.act_grad_pre + (int64_t)m1 * d.c_rs * szP;
     if (d.pre_out) b.pre_out = (char*)d.pre_out + (int64_t)m1 * d.c_rs * szC;
     int rc = demo_gemm_bf16_launch(a, s, 2566);
@@ -1100,6 +1125,7 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
   p.pre = d.act_grad_pre;
   p.pre_out = d.pre_out;
   p.pre_out_kind = d.pre_out ? d.pre_out_kind : 0;
+  p.dtRes = d.residual ? d.dtRes : 0;
   p.dephase = g_dephase;
   p.M = d.M; p.N = d.N; p.K = d.K;
   p.lda = d.a_rs; p.ldb = d.b_rs; p.ldc = d.c_rs;

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GArgs args) {
   const int64_t coff = z1 * d.sC1 + z2 * d.sC2;
   TC* C = reinterpret_cast<TC*>(d.C) + coff;
   const float* bias = d.bias ? d.bias + z1 * d.sBias1 + z2 * d.sBias2 : nullptr;
-  const float* res = d.residual ? d.residual + coff : nullptr;
+  const bool has_res = d.residual != nullptr;
 
   const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
   const int t = threadIdx.x;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GArgs args) {
         const float pre = d.dtPre == DEMO_BF16 ? ldg<bf16_t>(d.act_grad_pre, coff + ci) : ldg<float>(d.act_grad_pre, coff + ci);
         v *= act_grad(pre, d.act_grad_kind);
       }
-      if (res) v += res[ci];
+      if (has_res) v += d.dtRes == DEMO_BF16 ? ldg<bf16_t>(d.residual, coff + ci) : ldg<float>(d.residual, coff + ci);
       if (d.accumulate) v += io<TC>::ld(C + ci);
       io<TC>::st(C + ci, v);
     }

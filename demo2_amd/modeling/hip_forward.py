@@ -72,6 +72,8 @@ def trunk_forward(m, imgs: List[Tensor], cam: Optional[Tensor], T: torch.dtype, 
     act = ACT_QUICKGELU if g.arch == "clip" else ACT_GELU
     rates = g.drop_path if (drop_path and g.drop_path) else None
     m.last_drop_path = [] if rates else None
+    if T == torch.bfloat16 and m.bf16_residual and m.bf16_grad_stream and g.arch == "clip" and not rates:
+        return _trunk_blocks_bf16_residual(m, x, Bn, L, W, act, tape)
     if T == torch.bfloat16 and m.bf16_fwd_stream and m.bf16_grad_stream and g.arch == "clip":
         return _trunk_blocks_bf16_stream(m, x, Bn, L, W, act, tape)
     # ---- K3-K6: transformer blocks -------------------------------------------------------------------
@@ -130,6 +132,43 @@ def _trunk_tail(m, x_final: Tensor, y: Tensor, rf, tape: Optional[Tape]) -> Tens
     if tape is not None:
         tape.d.update(x_final=x_final, meanf=rf[1], rstdf=rf[2], y=y)
     return tokens
+
+
+def _trunk_blocks_bf16_residual(m, x32: Tensor, Bn: int, L: int, W: int, act: int, tape: Optional[Tape]) -> Tensor:
+    """Transformer blocks with the residual stream in bf16 and the adds INSIDE the GEMM epilogues (bf16 compute mode): the output
+    projection and fc2 read the stream as a bf16 residual operand and write the new stream in bf16 -- 134 instead of 268 MB of epilogue
+    traffic per product at B = 128 (the fp32 form is HBM-bound there: tools/gemm_cost.py, 126 us against 57 us without its epilogue) --
+    and the LayerNorms (forward and backward) read a bf16 stream.  One rounding of the stream to bf16 per residual add (24 per trunk)."""
+    g, P = m.geom, m.ptab
+    T = torch.bfloat16
+    dev = x32.device
+    sv = tape is not None
+    deriv = bool(m.save_act_deriv)
+    xs = ops.cast_f32_bf16(x32.view(-1), torch.empty(x32.numel(), device=dev, dtype=T)).view_as(x32)
+    for i in range(g.layers):
+        k = g.block_keys(i)
+        r1 = ops.layernorm_add_fwd(xs, None, P.f(k["ln1"] + ".weight"), P.f(k["ln1"] + ".bias"), g.ln_eps, save=sv)
+        h1 = r1[0] if sv else r1
+        qkv = ops.gemm(h1, P.w(k["qkv_w"], T), bias=P.f(k["qkv_b"]))
+        r2 = ops.attention_fwd(qkv, Bn, L, g.heads, save_lse=sv)
+        a = r2[0] if sv else r2
+        x1 = ops.gemm(a, P.w(k["proj_w"], T), bias=P.f(k["proj_b"]), residual=xs, out=None if sv else xs, out_dtype=T)
+        r3 = ops.layernorm_add_fwd(x1, None, P.f(k["ln2"] + ".weight"), P.f(k["ln2"] + ".bias"), g.ln_eps, save=sv)
+        h2 = r3[0] if sv else r3
+        if sv:
+            pre = torch.empty(Bn * L, 4 * W, device=dev, dtype=T)
+            u = ops.gemm(h2, P.w(k["fc1_w"], T), bias=P.f(k["fc1_b"]), act=act, pre_out=pre, pre_out_deriv=deriv)
+        else:
+            pre = None
+            u = ops.gemm(h2, P.w(k["fc1_w"], T), bias=P.f(k["fc1_b"]), act=act)
+        x2 = ops.gemm(u, P.w(k["fc2_w"], T), bias=P.f(k["fc2_b"]), residual=x1, out=None if sv else x1, out_dtype=T)
+        if sv:
+            tape.blocks.append(dict(x=xs, mean1=r1[1], rstd1=r1[2], h1=h1, qkv=qkv, lse=r2[1], a=a, x1=x1, mean2=r3[1], rstd2=r3[2],
+                                    h2=h2, pre=pre, pre_deriv=deriv, u=u, dp_a=None, dp_m=None))
+        xs = x2
+    rf = ops.layernorm_add_fwd(xs, None, P.f(g.k_lnpost + ".weight"), P.f(g.k_lnpost + ".bias"), g.ln_eps, save=sv)
+    y = rf[0] if sv else rf
+    return _trunk_tail(m, xs, y, rf, tape)
 
 
 def _trunk_blocks_bf16_stream(m, x32: Tensor, Bn: int, L: int, W: int, act: int, tape: Optional[Tape]) -> Tensor:

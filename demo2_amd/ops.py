@@ -98,11 +98,11 @@ def gemm_raw(A: Tensor, B: Tensor, Cout: Tensor, M: int, N: int, K: int, a_rs: i
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("bias must be fp32")
     if residual is not None:
-        if residual.dtype != torch.float32:
-            raise TypeError("residual must be fp32")
-        d.residual = residual.data_ptr() + c_off * 4
+        d.residual = residual.data_ptr() + c_off * residual.element_size()
+        d.dtRes = dt_code(residual.dtype)                 # fp32, or the bf16 residual stream of the bf16 compute mode
     else:
         d.residual = None
+        d.dtRes = 0
     d.M, d.N, d.K = M, N, K
     d.a_rs, d.a_cs, d.b_rs, d.b_cs, d.c_rs = a_rs, a_cs, b_rs, b_cs, c_rs
     d.dtA, d.dtB, d.dtC = dt_code(A.dtype), dt_code(B.dtype), dt_code(Cout.dtype)

@@ -48,7 +48,7 @@ typedef struct demo_gemm_desc {
   const void* B;
   void* C;
   const float* bias;      /* [N] fp32 or NULL */
-  const float* residual;  /* fp32, indexed like C (same ldc / batch strides), or NULL */
+  const void* residual;   /* dtype dtRes (fp32 by default), indexed like C (same ldc / batch strides), or NULL */
   int32_t M, N, K;
   int64_t a_rs, a_cs, b_rs, b_cs, c_rs;
   int32_t dtA, dtB, dtC;
@@ -63,6 +63,7 @@ typedef struct demo_gemm_desc {
   int32_t act_grad_kind;  /* DEMO_ACT_* whose derivative is applied */
   int32_t accumulate;     /* 1: C += result (fp32 C only) */
   void* pre_out;          /* optional: value BEFORE `act` (after alpha, bias), indexed and typed like C; saved for backward */
+  int32_t dtRes;          /* dtype of `residual`: DEMO_F32 (0, the default) or DEMO_BF16 -- the bf16 residual stream of the bf16 compute mode */
   int32_t pre_out_kind;   /* what pre_out receives: 0 = that pre-activation x, 1 = act'(x).  With 1 the backward product's epilogue is one
                              multiply (act_grad_kind DEMO_ACT_SAVED) instead of re-evaluating the derivative from x: the exponential and
                              the reciprocal are computed once, in the forward, where sigmoid(1.702x) / erf are needed anyway */

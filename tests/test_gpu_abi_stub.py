@@ -20,7 +20,7 @@ class GemmDesc(C.Structure):                      # struct demo_gemm_desc (inclu
                 ("sA1", C.c_int64), ("sA2", C.c_int64), ("sB1", C.c_int64), ("sB2", C.c_int64),
                 ("sC1", C.c_int64), ("sC2", C.c_int64), ("sBias1", C.c_int64), ("sBias2", C.c_int64),
                 ("act_grad_pre", C.c_void_p), ("dtPre", C.c_int32), ("act_grad_kind", C.c_int32), ("accumulate", C.c_int32),
-                ("pre_out", C.c_void_p), ("pre_out_kind", C.c_int32)]
+                ("pre_out", C.c_void_p), ("dtRes", C.c_int32), ("pre_out_kind", C.c_int32)]
 
 
 def test_documented_ctypes_stub_runs_the_mlp_linear():

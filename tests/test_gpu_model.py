@@ -145,7 +145,7 @@ def test_synthetic_map_parity():
     ids, per, nq = 30, 4, 60
     x, pid, camid = _synthetic_gallery(ids, per, 1.8, (256, 128))
     cam = torch.tensor(camid)
-    feats = {"oracle": [], torch.float32: [], torch.bfloat16: []}
+    feats = {"oracle": [], torch.float32: [], torch.bfloat16: [], "bf16+res": []}
     for i in range(0, ids * per, 8):
         xb = {k: v[i:i + 8] for k, v in x.items()}
         feats["oracle"].append(O.model_forward(sd, spec, xb, cam[i:i + 8]))
@@ -153,13 +153,22 @@ def test_synthetic_map_parity():
         for dt in (torch.float32, torch.bfloat16):
             with torch.no_grad():
                 feats[dt].append(m.set_compute_dtype(dt)(xd, cam_label=cam[i:i + 8].to(DEV)).cpu())
+        m.bf16_residual = True                                   # bf16 residual stream (adds in the GEMM epilogues)
+        with torch.no_grad():
+            feats["bf16+res"].append(m(xd, cam_label=cam[i:i + 8].to(DEV)).cpu())
+        m.bf16_residual = False
     res = {k: O.r1_map(torch.cat(v), pid, camid, nq, max_rank=10) for k, v in feats.items()}
-    (cmc_r, map_r), (cmc_f, map_f), (cmc_h, map_h) = res["oracle"], res[torch.float32], res[torch.bfloat16]
+    (cmc_r, map_r), (cmc_f, map_f), (cmc_h, map_h), (cmc_s, map_s) = res["oracle"], res[torch.float32], res[torch.bfloat16], res["bf16+res"]
+    fo, fh, fs = torch.cat(feats["oracle"]), torch.cat(feats[torch.bfloat16]), torch.cat(feats["bf16+res"])
+    print(f"\nfeature error vs oracle: bf16 mode rel {float((fh - fo).norm() / fo.norm()):.4f} max {float((fh - fo).abs().max()):.4f};  "
+          f"+ bf16 residual stream rel {float((fs - fo).norm() / fo.norm()):.4f} max {float((fs - fo).abs().max()):.4f};  "
+          f"mAP / Rank-1 with the bf16 residual stream {100 * map_s:.2f} / {100 * cmc_s[0]:.2f}")
     print(f"\nsynthetic eval (30 ids x 4, nq 60): mAP / Rank-1 / Rank-5 [%]  oracle fp32 {100 * map_r:.2f} / {100 * cmc_r[0]:.2f} / {100 * cmc_r[4]:.2f}"
           f"   HIP fp32 {100 * map_f:.2f} / {100 * cmc_f[0]:.2f} / {100 * cmc_f[4]:.2f}   HIP bf16 {100 * map_h:.2f} / {100 * cmc_h[0]:.2f} / {100 * cmc_h[4]:.2f}")
     assert 0.20 < map_r < 0.95 and 0.20 < cmc_r[0] < 0.95, (map_r, cmc_r[0])          # neither saturated nor degenerate
     assert abs(map_r - map_f) * 100 <= 0.1 and abs(cmc_r[0] - cmc_f[0]) * 100 <= 0.1, (map_r, map_f, cmc_r[0], cmc_f[0])
     assert abs(map_r - map_h) * 100 <= 0.1 and abs(cmc_r[0] - cmc_h[0]) * 100 <= 0.1, (map_r, map_h, cmc_r[0], cmc_h[0])
+    assert abs(map_r - map_s) * 100 <= 0.1 and abs(cmc_r[0] - cmc_s[0]) * 100 <= 0.1, (map_r, map_s, cmc_r[0], cmc_s[0])
     # the GPU evaluator on the GPU features gives the same figures as the numpy protocol on them
     from demo2_amd.utils.metrics import R1_mAP_eval
     ev = R1_mAP_eval(nq, max_rank=10, feat_norm="yes")

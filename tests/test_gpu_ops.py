@@ -120,6 +120,9 @@ def test_gemm_bf16_256_kernel_epilogues(M, N, K, reg_epi, tile):
         torch.testing.assert_close(pre.float().cpu(), ref + bias, rtol=1e-2, atol=1e-2)
         got = ops.gemm(ad, bd, bias=bias.to(DEV), residual=res.to(DEV), out_dtype=torch.float32, alpha=0.5)       # proj / fc2 forward
         torch.testing.assert_close(got.cpu(), 0.5 * ref + bias + res, rtol=1e-3, atol=1e-3)
+        r16 = res.bfloat16().to(DEV)                                                                               # the same on a bf16 residual stream,
+        got = ops.gemm(ad, bd, bias=bias.to(DEV), residual=r16, out=r16)                                           # updated in place
+        torch.testing.assert_close(got.float().cpu(), ref + bias + res.bfloat16().float(), rtol=1e-2, atol=2e-2)
         for kind in (ACT_QUICKGELU, ACT_GELU):                                                                  # MLP backward
             pr = rnd(M, N, seed=5).bfloat16().float().requires_grad_(True)
             act_ref(pr, kind).sum().backward()

@@ -137,8 +137,8 @@ def test_full_size_train_step_fp32_grads():
         assert e < 5e-3, (n, e)
 
 
-@pytest.mark.parametrize("B", [4, 16])
-def test_full_depth_bf16_gradients_against_fp32_oracle(B):
+@pytest.mark.parametrize("B,residual", [(4, False), (16, False), (16, True)])
+def test_full_depth_bf16_gradients_against_fp32_oracle(B, residual):
     """The BENCHMARKED mode (bf16 operands, fp32 accumulation, bf16 residual-gradient stream, saved activation derivative) at full
     depth: config A, 12 blocks, every parameter gradient against fp32 torch autograd of the CPU oracle.  Bounds are stated on the
     whole gradient and per parameter (cosine and relative error), over every parameter whose reference gradient is not rounding
@@ -148,6 +148,7 @@ def test_full_depth_bf16_gradients_against_fp32_oracle(B):
     perturbation -- the error there is uniform over all parameters (it enters at the heads); B = 16 shows the bf16 arithmetic itself."""
     cfg = make_cfg("RGBNT201")
     m, sd = build(cfg, 171, 4, torch.bfloat16)
+    m.bf16_residual = residual                       # the bf16 residual stream (GEMM-epilogue adds) on top of the bf16 products
     spec = spec_of(m)
     spec.hdm_dropout = 0.0
     x, cam = synth_batch(B, 256, 128, 4)
@@ -171,7 +172,7 @@ def test_full_depth_bf16_gradients_against_fp32_oracle(B):
     rv = sorted(rel.values())
     worst_rel = sorted(rel.items(), key=lambda kv: -kv[1])[:4]
     worst_cos = sorted(cos.items(), key=lambda kv: kv[1])[:4]
-    print(f"\nbf16 mode vs fp32 oracle, config A, 12 blocks, B={B}: whole gradient rel err {whole_rel:.4f}, cosine {whole_cos:.6f}; "
+    print(f"\nbf16 mode{' + bf16 residual stream' if residual else ''} vs fp32 oracle, config A, 12 blocks, B={B}: whole gradient rel err {whole_rel:.4f}, cosine {whole_cos:.6f}; "
           f"{len(live)}/{len(names)} live parameters: rel err median {rv[len(rv) // 2]:.4f} p90 {rv[int(0.9 * len(rv))]:.4f} max {rv[-1]:.4f}; "
           f"min cosine {worst_cos[0][1]:.5f}\n  worst rel: {worst_rel}\n  worst cos: {worst_cos}")
     # Measured on MI355X (round 2):  B = 16: whole gradient 2.9 % / cosine 0.99958, per parameter median 3.1 %, p90 4.2 %, max 14.4 %
@@ -447,6 +448,28 @@ def test_torch_optimizer_step_refreshes_bf16_shadow():
         k = m.geom.block_keys(0)["fc1_w"]
         assert torch.equal(P.wt(k, torch.bfloat16).float(), P.f(k).t().bfloat16().float())
     assert losses[2] < losses[0]                                    # the same batch three times: the loss goes down
+
+
+def test_bf16_residual_stream_option_trains_like_the_fp32_stream():
+    """DEMO_BF16_RESIDUAL: residual stream in bf16 with the adds inside the GEMM epilogues (proj / fc2 read a bf16 residual and write the
+    bf16 stream in place at inference).  Same loss and gradients as the fp32-stream bf16 mode up to bf16 noise, same eval features."""
+    cfg = small_cfg("clip")
+    x, cam = synth_batch(8, 64, 32, 3)
+    xd, camd = {k: v.to(DEV) for k, v in x.items()}, cam.to(DEV)
+    target = torch.tensor([0, 0, 1, 1, 2, 2, 3, 3], device=DEV)
+    res = []
+    for on in (False, True):
+        m, _ = build(cfg, 11, 3, torch.bfloat16)
+        m.bf16_residual = on
+        with torch.no_grad():
+            feat = m.eval()(xd, cam_label=camd).cpu()
+        ts = TrainStep(m.train(), cfg, 1, optimizer=False)
+        loss = ts.step(xd, target, camd).item()
+        res.append((feat, loss, m.grad_buffer().detach().cpu().clone()))
+    (f0, l0, g0), (f1, l1, g1) = res
+    assert (f0 - f1).abs().max() < 0.1 and (f0 - f1).norm() / f0.norm() < 0.03
+    assert abs(l0 - l1) < 0.02 * abs(l0) + 0.01
+    assert ((g0 - g1).norm() / g0.norm()).item() < 0.1
 
 
 def test_bf16_forward_stream_option_trains_like_the_default():
