@@ -74,6 +74,7 @@ PROTOTYPES = {
     "demo_batchnorm_fwd": [_P, _P, _P, _P, _P, _I, _F, _F, _P, _I, _P, _P, _I, _I, _I, _I, _I, _L, _L, _P, _P],
     "demo_attention_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "demo_attention_set_variant": [C.c_int],
+    "demo_layernorm_set_lp8": [C.c_int],
     "demo_pife_pool_cat": [_P, _I, _P, _I, _I, _I, _P],
     "demo_set_token0": [_P, _I, _P, _L, _I, _I, _I, _P],
     "demo_get_token0": [_P, _I, _P, _L, _I, _I, _I, _P],

@@ -218,6 +218,114 @@ __global__ __launch_bounds__(256) void layernorm_bwd_cols_kernel(const TDY* __re
   if (db) { atomicAdd(&db[c4], adb.x); atomicAdd(&db[c4 + 1], adb.y); atomicAdd(&db[c4 + 2], adb.z); atomicAdd(&db[c4 + 3], adb.w); }
 }
 
+// All-bf16 stream form of the column-owner backward (bf16 residual stream AND bf16 gradient stream: dy, x, the running gradient and
+// the result are all bf16): a thread owns EIGHT columns, so every access is 16 B, and walks R = 4 rows per step (R = 8 spills at three waves per SIMD) with all 3R loads in
+// flight -- 192 B per thread against 96 B for the 4-column form on the same operands, which on this latency-bound kernel (see above)
+// ran SLOWER with bf16 x than with fp32 x (106 vs 90 us at 49536 x 768) although it moves fewer bytes.  128-thread workgroups (D <= 1024).
+__device__ __forceinline__ void bf16x8_unpack(const uint4 r, float (&f)[8]) {
+  f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+  f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+  f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+  f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+template <int R>
+__global__ __launch_bounds__(128, 3) void layernorm_bwd_lp8_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                const float* __restrict__ w, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
+                                                                bf16_t* __restrict__ out, float* __restrict__ dw, float* __restrict__ db,
+                                                                float* __restrict__ part, int M, int D, int rows_per_block) {
+  __shared__ float red[2][R][2][2];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int c8 = t * 8;
+  const bool colok = c8 < D;
+  float w8[8], adw[8], adb[8];
+  {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 a = colok ? *reinterpret_cast<const float4*>(w + c8) : z, b = colok ? *reinterpret_cast<const float4*>(w + c8 + 4) : z;
+    w8[0] = a.x; w8[1] = a.y; w8[2] = a.z; w8[3] = a.w; w8[4] = b.x; w8[5] = b.y; w8[6] = b.z; w8[7] = b.w;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) adw[e] = adb[e] = 0.f;
+  const float inv_d = 1.f / (float)D;
+  const int r0 = blockIdx.x * rows_per_block;
+  const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+  int par = 0;
+  for (int rc = 0; rc < rows_per_block; rc += R, par ^= 1) {
+    const int rbase = r0 + rc;
+    if (rbase >= M) break;
+    uint4 xr[R], dr[R], pr[R];
+    float mu[R], rs[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = rbase + r;
+      const bool rowok = row < M, ok = rowok && colok;      // rowok is workgroup-uniform
+      const int64_t o = (int64_t)row * D;
+      mu[r] = rowok ? mean[row] : 0.f;
+      rs[r] = rowok ? rstd[row] : 0.f;
+      xr[r] = ok ? *reinterpret_cast<const uint4*>((x + o) + c8) : z4;
+      dr[r] = ok ? *reinterpret_cast<const uint4*>((dy + o) + c8) : z4;
+      pr[r] = (dres && ok) ? *reinterpret_cast<const uint4*>((dres + o) + c8) : z4;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float xf[8], df[8];
+      bf16x8_unpack(xr[r], xf);
+      bf16x8_unpack(dr[r], df);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float g = df[e] * w8[e];
+        s1 += g;
+        s2 = fmaf(g, (xf[e] - mu[r]) * rs[r], s2);
+      }
+      s1 = wave_sum(s1);
+      s2 = wave_sum(s2);
+      if (lane == 0) {
+        red[par][r][0][wv] = s1;
+        red[par][r][1][wv] = s2;
+      }
+      __builtin_amdgcn_sched_barrier(0);            // one row at a time: the raw rows stay packed (12 registers each) until they are used
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = rbase + r;
+      const float s1 = (red[par][r][0][0] + red[par][r][0][1]) * inv_d, s2 = (red[par][r][1][0] + red[par][r][1][1]) * inv_d;
+      float xf[8], df[8], pf[8], o[8];
+      bf16x8_unpack(xr[r], xf);
+      bf16x8_unpack(dr[r], df);
+      bf16x8_unpack(pr[r], pf);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (xf[e] - mu[r]) * rs[r];
+        adw[e] = fmaf(df[e], xh, adw[e]);
+        adb[e] += df[e];
+        o[e] = pf[e] + rs[r] * (df[e] * w8[e] - s1 - xh * s2);
+      }
+      if (row < M && colok) {
+        uint4 q;
+        q.x = pack_bf16x2(o[0], o[1]); q.y = pack_bf16x2(o[2], o[3]); q.z = pack_bf16x2(o[4], o[5]); q.w = pack_bf16x2(o[6], o[7]);
+        *reinterpret_cast<uint4*>((out + (int64_t)row * D) + c8) = q;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (!colok) return;
+  if (part) {
+    float* prow = part + (int64_t)blockIdx.x * 2 * D;
+    *reinterpret_cast<float4*>(prow + c8) = make_float4(adw[0], adw[1], adw[2], adw[3]);
+    *reinterpret_cast<float4*>(prow + c8 + 4) = make_float4(adw[4], adw[5], adw[6], adw[7]);
+    *reinterpret_cast<float4*>(prow + D + c8) = make_float4(adb[0], adb[1], adb[2], adb[3]);
+    *reinterpret_cast<float4*>(prow + D + c8 + 4) = make_float4(adb[4], adb[5], adb[6], adb[7]);
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (dw) atomicAdd(&dw[c8 + e], adw[e]);
+    if (db) atomicAdd(&db[c8 + e], adb[e]);
+  }
+}
+
 // Backward, row-owner form (any D up to 2048): one wave per row for dx; dw/db accumulated per block in LDS then atomically
 // added into fp32 dw/db (D floats each; D*gridDim atomics spread over D addresses).
 // NV = float4 per lane (compile time: D = 768 -> 3), so that only the registers a row needs are allocated and 8 waves per
@@ -564,6 +672,9 @@ extern "C" int demo_layernorm_bwd(const void* dy, int32_t dtDy, const float* x, 
   return 0;
 }
 
+static int g_ln_lp8 = 1;      // tuning hook: 0 = the 4-column kernel also for all-bf16 streams
+extern "C" int demo_layernorm_set_lp8(int on) { g_ln_lp8 = on != 0; return 0; }
+
 extern "C" int demo_layernorm_bwd_lp(const void* dy, int32_t dtDy, const void* x, int32_t dtX, const float* w, const float* mean, const float* rstd,
                                      const void* dres_bf16, void* dx_bf16, float* dw, float* db, float* workspace, int64_t workspace_elems,
                                      int32_t M, int32_t D, void* stream) {
@@ -577,7 +688,10 @@ extern "C" int demo_layernorm_bwd_lp(const void* dy, int32_t dtDy, const void* x
 #define LN_LP(TDY_, TX_)                                                                                                               \
   hipLaunchKernelGGL((layernorm_bwd_cols_kernel<TDY_, 4, false, true, TX_>), dim3((unsigned)nblk), blk, 0, s, (const TDY_*)dy, (const TX_*)x, w, \
                      mean, rstd, (float*)nullptr, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block, (const bf16_t*)dres_bf16)
-  if (dtDy == DEMO_BF16) { if (dtX == DEMO_BF16) LN_LP(bf16_t, bf16_t); else LN_LP(bf16_t, float); }
+  if (dtDy == DEMO_BF16 && dtX == DEMO_BF16 && D % 8 == 0 && g_ln_lp8)      // all-bf16 streams: 8 columns per thread, 16-B accesses
+    hipLaunchKernelGGL(layernorm_bwd_lp8_kernel<4>, dim3((unsigned)nblk), dim3(128), 0, s, (const bf16_t*)dy, (const bf16_t*)x, w, mean, rstd,
+                       (const bf16_t*)dres_bf16, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block);
+  else if (dtDy == DEMO_BF16) { if (dtX == DEMO_BF16) LN_LP(bf16_t, bf16_t); else LN_LP(bf16_t, float); }
   else { if (dtX == DEMO_BF16) LN_LP(float, bf16_t); else LN_LP(float, float); }
 #undef LN_LP
   DEMO_LAUNCH_CHECK("demo_layernorm_bwd_lp");

@@ -251,6 +251,7 @@ int64_t demo_gemm_tn_workspace(int32_t Mo, int32_t No, int32_t Kr);
 /* colsum (optional, fp32 [Mo]): colsum[m] += sum_r A[r,m] -- the bias gradient of the same Linear, computed by the waves
  * that already hold the A fragments (no extra pass over dY). */
 /* Self-attention backward (same packing as demo_attention_fwd; lse from the forward): dqkv (Bn*L, 3D). */
+int demo_layernorm_set_lp8(int on);    /* tuning hook: 1 (default) = demo_layernorm_bwd_lp takes the 8-column kernel when dy and x are both bf16 */
 int demo_attention_set_variant(int v); /* tuning hook: 1 (default) = forward with K/V only in LDS (4 workgroups per CU), 0 = the round-1 form */
 int demo_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int32_t Bn,
                        int32_t L, int32_t H, int32_t dh, int32_t dt, void* stream);
