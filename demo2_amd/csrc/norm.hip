@@ -326,6 +326,74 @@ __global__ __launch_bounds__(128, 3) void layernorm_bwd_lp8_kernel(const bf16_t*
   }
 }
 
+// LayerNorm forward on a bf16 stream, bf16 output (bf16 residual stream): HALF a wave per row, a lane owns 8-column chunks
+// lane32 + 32 i (16-B loads and stores; D = 768: three chunks), two rows per wave, all of a lane's loads issued first.  The
+// wave-per-row form above moves 24 B per lane and row on this operand and takes as long on 152 MB as on the fp32 stream's 229 MB.
+constexpr int LN8_MAXC = 4;                        // D <= 32 * 8 * 4 = 1024
+__device__ __forceinline__ float half_wave_sum(float v) {      // sum over the 32 lanes of this half of the wave
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return v + __shfl_xor(v, 16, 64);
+}
+__global__ __launch_bounds__(256) void layernorm_fwd_lp8_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ b, float eps, bf16_t* __restrict__ y,
+                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int D) {
+  const int l32 = threadIdx.x & 31;
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const bool rowok = row < M;
+  const int64_t ro = (int64_t)(rowok ? row : M - 1) * D;      // (clamped: the DPP reductions need every lane of the wave)
+  const int nch = D >> 3;
+  uint4 raw[LN8_MAXC];
+#pragma unroll
+  for (int i = 0; i < LN8_MAXC; ++i) {
+    const int c = l32 + 32 * i;
+    raw[i] = c < nch ? *reinterpret_cast<const uint4*>(x + ro + c * 8) : make_uint4(0u, 0u, 0u, 0u);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN8_MAXC; ++i) {
+    float f[8];
+    bf16x8_unpack(raw[i], f);
+    s += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+  }
+  const float mean = half_wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN8_MAXC; ++i) {
+    if (l32 + 32 * i < nch) {
+      float f[8];
+      bf16x8_unpack(raw[i], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q = fmaf(f[e] - mean, f[e] - mean, q);
+    }
+  }
+  const float rstd = rsqrtf(half_wave_sum(q) / (float)D + eps);
+  if (!rowok) return;
+  if (l32 == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < LN8_MAXC; ++i) {
+    const int c = l32 + 32 * i;
+    if (c < nch) {
+      float f[8];
+      bf16x8_unpack(raw[i], f);
+      const float4 g0 = *reinterpret_cast<const float4*>(w + c * 8), g1 = *reinterpret_cast<const float4*>(w + c * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(b + c * 8), b1 = *reinterpret_cast<const float4*>(b + c * 8 + 4);
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = fmaf((f[e] - mean) * rstd, gg[e], bb[e]);
+      uint4 r;
+      r.x = pack_bf16x2(o[0], o[1]); r.y = pack_bf16x2(o[2], o[3]); r.z = pack_bf16x2(o[4], o[5]); r.w = pack_bf16x2(o[6], o[7]);
+      *reinterpret_cast<uint4*>(y + (int64_t)row * D + c * 8) = r;
+    }
+  }
+}
+
 // Backward, row-owner form (any D up to 2048): one wave per row for dx; dw/db accumulated per block in LDS then atomically
 // added into fp32 dw/db (D floats each; D*gridDim atomics spread over D addresses).
 // NV = float4 per lane (compile time: D = 768 -> 3), so that only the registers a row needs are allocated and 8 waves per
@@ -592,6 +660,9 @@ extern "C" int demo_layernorm_fwd(const float* x, const float* w, const float* b
   return 0;
 }
 
+static int g_ln_lp8 = 1;      // tuning hook: 0 = the wave-per-row / 4-column kernels also for all-bf16 streams
+extern "C" int demo_layernorm_set_lp8(int on) { g_ln_lp8 = on != 0; return 0; }
+
 extern "C" int demo_layernorm_add_fwd(const void* x, int32_t dtX, const void* add, int32_t dtAdd, void* xsum_out, const float* w, const float* b,
                                       float eps, void* y, int32_t dtY, float* mean, float* rstd, int32_t M, int32_t D, void* stream) {
   DEMO_REQUIRE(D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "demo_layernorm_add_fwd: D=%d must be a multiple of 4 and <= %d", D, 64 * 4 * LN_MAXV);
@@ -599,7 +670,10 @@ extern "C" int demo_layernorm_add_fwd(const void* x, int32_t dtX, const void* ad
   DEMO_REQUIRE(dtY == DEMO_BF16 && (!add || dtAdd == DEMO_BF16), "demo_layernorm_add_fwd: y and add are bf16 (the bf16 compute mode's activations)");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)cdiv64(M, 4));
-  if (dtX == DEMO_BF16)
+  if (dtX == DEMO_BF16 && !add && !xsum_out && D % 8 == 0 && D <= 32 * 8 * LN8_MAXC && g_ln_lp8)       // plain LayerNorm of a bf16 stream
+    hipLaunchKernelGGL(layernorm_fwd_lp8_kernel, dim3((unsigned)cdiv64(M, 8)), dim3(256), 0, s, (const bf16_t*)x, w, b, eps, (bf16_t*)y, mean, rstd,
+                       M, D);
+  else if (dtX == DEMO_BF16)
     hipLaunchKernelGGL((layernorm_add_fwd_kernel<bf16_t, bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)add, (bf16_t*)xsum_out,
                        w, b, eps, (bf16_t*)y, mean, rstd, M, D);
   else
@@ -671,9 +745,6 @@ extern "C" int demo_layernorm_bwd(const void* dy, int32_t dtDy, const float* x, 
   }
   return 0;
 }
-
-static int g_ln_lp8 = 1;      // tuning hook: 0 = the 4-column kernel also for all-bf16 streams
-extern "C" int demo_layernorm_set_lp8(int on) { g_ln_lp8 = on != 0; return 0; }
 
 extern "C" int demo_layernorm_bwd_lp(const void* dy, int32_t dtDy, const void* x, int32_t dtX, const float* w, const float* mean, const float* rstd,
                                      const void* dres_bf16, void* dx_bf16, float* dw, float* db, float* workspace, int64_t workspace_elems,

@@ -285,6 +285,10 @@ def test_layernorm_bwd_lp_stream(M, D):
     for lp8 in (1, 0):
         _lib.load().demo_layernorm_set_lp8(lp8)
         try:
+            yv, mv, rv = ops.layernorm_add_fwd(xb.to(DEV), None, w.detach().to(DEV), b.detach().to(DEV), 1e-5, save=True)     # forward: half-wave / wave per row
+            torch.testing.assert_close(yv.float().cpu(), O.layer_norm(xb.float(), w.detach(), b.detach(), 1e-5), rtol=1e-2, atol=1e-2)
+            torch.testing.assert_close(mv.cpu(), xb.float().mean(1), rtol=1e-5, atol=1e-5)
+            torch.testing.assert_close(rv.cpu(), torch.rsqrt(xb.float().var(1, unbiased=False) + 1e-5), rtol=1e-4, atol=1e-5)
             dw, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
             buf = res.to(DEV).clone()
             out = ops.layernorm_bwd_lp(dy.to(DEV), xb.to(DEV), w.detach().to(DEV), mean, rstd, buf, buf, dw=dw, db=db)

@@ -30,7 +30,8 @@ def bwd(x, lp8):
 
 
 arms = [("fwd fp32 x -> bf16 (229 MB)", lambda: ops.layernorm_fwd(x32, w, b, 1e-5, torch.bfloat16, save=True), 229e6),
-        ("fwd bf16 x -> bf16 (152 MB)", lambda: ops.layernorm_add_fwd(x16, None, w, b, 1e-5, save=True), 152e6),
+        ("fwd bf16 x -> bf16, wave per row (152 MB)", lambda: (lib.demo_layernorm_set_lp8(0), ops.layernorm_add_fwd(x16, None, w, b, 1e-5, save=True)), 152e6),
+        ("fwd bf16 x -> bf16, half wave per row (152 MB)", lambda: (lib.demo_layernorm_set_lp8(1), ops.layernorm_add_fwd(x16, None, w, b, 1e-5, save=True)), 152e6),
         ("bwd lp, fp32 x, 4 cols (380 MB)", lambda: bwd(x32, 1), 380e6),
         ("bwd lp, bf16 x, 4 cols (304 MB)", lambda: bwd(x16, 0), 304e6),
         ("bwd lp, bf16 x, 8 cols (304 MB)", lambda: bwd(x16, 1), 304e6)]
@@ -51,4 +52,4 @@ for _ in range(25):
 lib.demo_layernorm_set_lp8(1)
 for n, _, nb in arms:
     med = statistics.median(t[n])
-    print(f"{n:36s} median {med:7.1f} us  min {min(t[n]):7.1f} us  {nb / med / 1e6:5.2f} TB/s")
+    print(f"{n:48s} median {med:7.1f} us  min {min(t[n]):7.1f} us  {nb / med / 1e6:5.2f} TB/s")
