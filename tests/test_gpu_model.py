@@ -150,13 +150,13 @@ def test_synthetic_map_parity():
         xb = {k: v[i:i + 8] for k, v in x.items()}
         feats["oracle"].append(O.model_forward(sd, spec, xb, cam[i:i + 8]))
         xd = {k: v.to(DEV) for k, v in xb.items()}
+        m.bf16_residual = False                                  # fp32 residual stream: fp32 mode, and bf16 products on an fp32 stream
         for dt in (torch.float32, torch.bfloat16):
             with torch.no_grad():
                 feats[dt].append(m.set_compute_dtype(dt)(xd, cam_label=cam[i:i + 8].to(DEV)).cpu())
-        m.bf16_residual = True                                   # bf16 residual stream (adds in the GEMM epilogues)
+        m.bf16_residual = True                                   # the default bf16 mode: bf16 residual stream (adds in the GEMM epilogues)
         with torch.no_grad():
             feats["bf16+res"].append(m(xd, cam_label=cam[i:i + 8].to(DEV)).cpu())
-        m.bf16_residual = False
     res = {k: O.r1_map(torch.cat(v), pid, camid, nq, max_rank=10) for k, v in feats.items()}
     (cmc_r, map_r), (cmc_f, map_f), (cmc_h, map_h), (cmc_s, map_s) = res["oracle"], res[torch.float32], res[torch.bfloat16], res["bf16+res"]
     fo, fh, fs = torch.cat(feats["oracle"]), torch.cat(feats[torch.bfloat16]), torch.cat(feats["bf16+res"])
