@@ -8,8 +8,11 @@ State-dict names are the reference's (so its .pth files load via load_param); th
 schedule in hip_forward.py.  In this fork of the reference the HDM/ATMoE wiring exists only as constructor code
 (make_model.py:131-138) plus documentation; the forward below re-instates it exactly as SURVEY.md section 3.2
 reconstructs it: backbone x3 (make_model.py:247-249) -> PIFE reduce (:301-303) -> ori (:370) -> GeneralFusion
-(AttnMOE.py:202-224) -> BNNeck heads (:134-138,174-194).  return_pattern 3 concatenates [ori, moe]
-(reference drawing/DeMo_overall_diagram_prompt.md:153-155; the order does not change distances / mAP).
+(AttnMOE.py:202-224) -> BNNeck heads (:134-138,174-194).  return_pattern 3 concatenates [moe, ori]: the fork's forward no
+longer concatenates anything (make_model.py:425-439), so the order is taken from the one piece of code on the call surface that
+names it -- the trainer's own message for this pattern, "Current is the [moe,ori] feature testing!" (engine/processor.py:220, :259) --
+which is also what SURVEY.md section 3.2 reconstructs; the [ori, .] order of drawing/DeMo_overall_diagram_prompt.md:153-155 describes
+the SDTPS variant, not this path.  (Euclidean distances, hence mAP / CMC, do not depend on the order.)
 
 MI355X-first memory layout: every parameter is a view into ONE flat fp32 buffer (and every float buffer into one
 flat stats buffer); gradients accumulate into one flat fp32 buffer of the same layout, so data-parallel
@@ -538,7 +541,7 @@ class DeMo(_Holder):
             return ori
         if return_pattern == 2:
             return moe
-        return torch.cat([ori, moe], dim=-1)
+        return torch.cat([moe, ori], dim=-1)                             # "[moe,ori]": engine/processor.py:220 (see the module docstring)
 
     def _train_outputs_dgaf(self, feat, globs, tape):
         """(dgaf_score, dgaf_feat) [+ per-modality (score, global) pairs when DIRECT = 0]  (make_model.py:853-862)"""

@@ -394,7 +394,7 @@ def model_forward(sd: SD, spec: Spec, x: Dict[str, Tensor], cam_label: Optional[
         return ori
     if return_pattern == 2:
         return moe_feat
-    return torch.cat([ori, moe_feat], -1)
+    return torch.cat([moe_feat, ori], -1)                             # "[moe,ori]" (engine/processor.py:220)
 
 
 # --------------------------------------------------------------------------
