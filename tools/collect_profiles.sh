@@ -1,0 +1,34 @@
+#!/bin/bash
+# Everything profiles/rNN_* is made from, in one pass on ONE box (run on the GPU box; outputs under gpurun_out/prof/):
+#   bench lines (default, forward, side configurations), rocprofv3 kernel stats of the default command, the counter passes
+#   (HBM traffic, L2, MFMA pipe / clock), and the micro-benchmarks quoted in DESIGN.md.
+set -o pipefail
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+O=gpurun_out/prof
+rm -rf $O; mkdir -p $O
+step() { echo "== $*" | tee -a $O/log.txt; }
+step bench default;        python bench.py > $O/bench_default.json 2> $O/bench_default.err || echo FAILED
+step kernel stats;         rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o t -- python3 bench.py > $O/bench_default_under_rocprof.json 2> $O/stats.err || echo FAILED
+step pmc fetch;            rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_F -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_F.log 2>&1 || echo FAILED
+step pmc write;            rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_W -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_W.log 2>&1 || echo FAILED
+python tools/pmc_traffic.py $O/pmc_F $O/pmc_W > $O/hbm_traffic_pmc.json || echo FAILED
+step pmc l2 a;             rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_BUBBLE_sum --output-format csv -d $O/pmc_l2a -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_l2a.log 2>&1 || echo FAILED
+step pmc l2 b;             rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum TCC_REQ_sum TCC_READ_sum --output-format csv -d $O/pmc_l2b -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_l2b.log 2>&1 || echo FAILED
+python tools/pmc_l2.py $O/pmc_l2a $O/pmc_l2b > $O/l2_pmc.json || echo FAILED
+step pmc sq;               rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmc_sq -o s -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_sq.log 2>&1 || echo FAILED
+step pmc grbm;             rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_grbm -o g -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_grbm.log 2>&1 || echo FAILED
+python tools/pmc_mfma.py $O/pmc_sq $O/pmc_grbm > $O/mfma_pmc.json || echo FAILED
+step bench fwd b64;        python bench.py --mode fwd --no-cpu-baseline > $O/bench_fwd_b64.json 2> $O/bench_fwd.err || echo FAILED
+step bench RGBNT100;       python bench.py --config RGBNT100 --no-cpu-baseline > $O/bench_rgbnt100.json 2> $O/bench_rgbnt100.err || echo FAILED
+step bench vit;            python bench.py --config vit --no-cpu-baseline > $O/bench_vit.json 2> $O/bench_vit.err || echo FAILED
+step bench dgaf;           python bench.py --fusion dgaf --no-cpu-baseline > $O/bench_dgaf.json 2> $O/bench_dgaf.err || echo FAILED
+step fwd B=1;              python bench.py --mode fwd --batch 1 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_fwd_b1.json 2>/dev/null || echo FAILED
+step gemm cost;            python tools/gemm_cost.py > $O/gemm_cost.txt 2>&1 || echo FAILED
+step attention;            python tools/bench_attn.py > $O/bench_attn.txt 2>&1 || echo FAILED
+step layernorm;            python tools/bench_ln.py > $O/bench_ln.txt 2>&1 || echo FAILED
+step store probe;          tools/probes/store_probe > $O/store_probe.txt 2>&1 || echo FAILED
+# keep only the summaries (the raw traces are tens of MB)
+cp $O/stats/t_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
+rm -rf $O/stats $O/pmc_F $O/pmc_W $O/pmc_l2a $O/pmc_l2b $O/pmc_sq $O/pmc_grbm
+ls -la $O
