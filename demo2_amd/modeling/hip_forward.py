@@ -377,8 +377,7 @@ def atmoe_forward(m, feats: Tensor, B: int, training: bool, tape: Optional[Tape]
         e1 = "generalFusion.moe.experts.0.expertHead.1.mlp."
         es = P.off(e1 + "0.weight") - P.off(e0 + "0.weight")
         ss = S.off(e1 + "2.running_mean") - S.off(e0 + "2.running_mean")
-        ws = (m.workspace("atmoe_x2", (B, C), torch.float32), m.workspace("atmoe_k", (B, 7, C), torch.float32),
-              m.workspace("atmoe_y", (B, 7 * C), torch.float32))
+        ws = m._ws.setdefault(("atmoe_eval", B), {})          # two alternating zeroed accumulators + the expert-output workspace
         bn1 = (P.f(gk + "linear_re.2.weight"), P.f(gk + "linear_re.2.bias"), S.f(gk + "linear_re.2.running_mean"),
                S.f(gk + "linear_re.2.running_var"))
         return ops.atmoe_eval_fwd(feats, P.f(gk + "linear_re.0.weight"), P.f(gk + "linear_re.0.bias"), bn1, P.f(gk + "q_.weight"),

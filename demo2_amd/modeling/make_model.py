@@ -171,9 +171,8 @@ class DeMo(_Holder):
         self._frozen = None
         self._errors = None
         self._wcache = {}
-        # inference: ATMoE in two launches (csrc/atmoe.hip).  Opt-in for now: measured SLOWER than the multi-launch schedule in its first form
-        # (eval forward B = 1 / 8 / 64: 1.81 / 2.81 / 7.34 ms against 1.69 / 2.43 / 6.99 ms -- its long-K gate tiles run on 16 workgroups)
-        self.fused_atmoe_eval = os.environ.get("DEMO_FUSED_ATMOE_EVAL", "0") == "1"
+        # inference: ATMoE in two launches (csrc/atmoe.hip); DEMO_FUSED_ATMOE_EVAL=0 restores the 8-launch schedule training uses
+        self.fused_atmoe_eval = os.environ.get("DEMO_FUSED_ATMOE_EVAL", "1") != "0"
         self.grad_sync = None            # set by demo2_amd.dist.GradSync for data-parallel runs
         self.overlap_dw = os.environ.get("DEMO_OVERLAP_DW", "0") == "1"   # opt-in: weight-gradient GEMMs on a side stream (hip_backward.py; measured +1.4 %)
         self._side = None

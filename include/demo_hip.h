@@ -294,17 +294,20 @@ int demo_tokens_grad(const float* dtok, const float* dcls, int64_t cls_ld, const
 
 /* ---- ATMoE at inference, fused (AttnMOE.py:50-68 gate, :24-47 experts, :85-121 MoM.forward) --------------------------------------
  * Eval mode only (every BatchNorm1d is the affine map of its running statistics): the whole module in TWO launches --
- * stage 1: x2 = BN(QuickGELU(W1 [f_1..f_7] + b1)), k_j = Wk f_j and the 7*H experts' y_jh = BN(QuickGELU(W_hj f_j[h] + b_hj)) as
- * independent LDS-staged 64-column tiles of one grid; stage 2, per head: q_h = Wq[h] x2, g_hj = softmax_j(q_h . k_jh / sqrt(d)),
- * moe[b, j*C + h*d + n] = g_hj * y_jh[n].  feats (B,7,C) fp32; weights are pointers into the flat parameter / statistics buffers:
- * ew / eb / ebn_w / ebn_b address expert (h=0, j=0), expert (h, j) sits (7h + j) * expert_stride floats further (stat_stride for the
- * running mean / var); ws_x2 (B,C), ws_k (B,7,C), ws_y (B,7C) are caller-owned workspaces; gates (B,H,7) optional.
- * demo_atmoe_eval_supported: 1 if (C, H) fits the kernels (C and d = C/H multiples of 32, d <= 128). */
+ * stage 1: independent LDS-staged tiles of 64 output columns x <= 256 of the reduction: the gate's linear_re.0 (raw sums) and the keys
+ * k_j = Wk f_j are ADDED into acc (fp32 atomics: the 7C-long reduction is cut so that no workgroup streams more than 64 KB of weights),
+ * the 7*H experts y_jh = BN(QuickGELU(W_hj f_j[h] + b_hj)) are finished in place; stage 2, per head and 16 samples:
+ * x2 = BN(QuickGELU(x1 + b1)), q_h = Wq[h] x2, g_hj = softmax_j(q_h . k_jh / sqrt(d)), moe[b, j*C + h*d + n] = g_hj * y_jh[n].
+ * feats (B,7,C) fp32; weights are pointers into the flat parameter / statistics buffers: ew / eb / ebn_w / ebn_b address expert
+ * (h=0, j=0), expert (h, j) sits (7h + j) * expert_stride floats further (stat_stride for the running mean / var).
+ * acc_zeroed: B*8C floats {x1 (B,C) | k (B,7,C)}, ZERO on entry (caller-owned); acc_next (optional): a second such buffer that stage 2
+ * zeroes for the next call -- alternating two buffers, the caller never needs a memset.  ws_y (B,7C) workspace; gates (B,H,7) optional.
+ * demo_atmoe_eval_supported: 1 if (C, H) fits the kernels (d = C/H a multiple of 16, <= 128). */
 int demo_atmoe_eval_supported(int32_t C, int32_t H);
 int demo_atmoe_eval_fwd(const float* feats, const float* w1, const float* b1, const float* bn1_w, const float* bn1_b,
                         const float* bn1_mean, const float* bn1_var, const float* wq, const float* wk, const float* ew,
                         const float* eb, const float* ebn_w, const float* ebn_b, const float* ebn_mean, const float* ebn_var,
-                        int64_t expert_stride, int64_t stat_stride, float eps, float* ws_x2, float* ws_k, float* ws_y, float* moe,
+                        int64_t expert_stride, int64_t stat_stride, float eps, float* acc_zeroed, float* acc_next, float* ws_y, float* moe,
                         float* gates, int32_t B, int32_t C, int32_t H, void* stream);
 
 /* ---- training losses: value and gradient in one launch -----------------------------------------
