@@ -316,6 +316,12 @@ class DeMo(_Holder):
             self._plist = [p for p in self.parameters()]
         return sum(p._version for p in self._plist)
 
+    def _forward_version(self) -> int:
+        """The parameter version refresh_shadow() saw at the start of this forward (summing 400 tensor versions costs ~0.1 ms of
+        host time, which a B=1 eval forward of 1.7 ms notices when it is done three times)."""
+        sv = self.ptab.shadow_version
+        return sv[0] if isinstance(sv, tuple) else self._param_version()
+
     def refresh_shadow(self):
         """Compute-dtype copies of the weights (bf16 shadow for the MFMA GEMMs, transposed CLIP proj);
         one cast launch whenever any parameter changed in place (optimizer step, load_state_dict)."""
@@ -441,12 +447,12 @@ class DeMo(_Holder):
     def weight_cache(self, name, T):
         """Quantities that depend on the weights only (HDM / DGAF query projections and folded keys), valid for one parameter version on
         one device and compute dtype; None when absent or stale."""
-        ver = (self._param_version(), T, self.ptab.flat.device)
+        ver = (self._forward_version(), T, self.ptab.flat.device)
         hit = self._wcache.get(name)
         return hit[1] if hit is not None and hit[0] == ver else None
 
     def weight_cache_put(self, name, T, value):
-        self._wcache[name] = ((self._param_version(), T, self.ptab.flat.device), value)
+        self._wcache[name] = ((self._forward_version(), T, self.ptab.flat.device), value)
 
     def device_errors(self) -> ops.DeviceErrors:
         """The model's device error word (out-of-range camera ids / labels reported by the kernels, see ops.DeviceErrors)."""
