@@ -40,6 +40,7 @@ struct FArgs {
   int ntm, ntn;
   int group_m;                 // 256^2 kernel: row panels per tile-order group
   int dephase;                 // 256^2 kernel, tuning hook: first-round workgroups start ((id >> 3) & 3) * dephase * 64 clocks late
+  int colslice;                // 256^2 kernel: > 1 = every XCD keeps to ntn / colslice weight panels for the whole launch (see the kernel)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -174,6 +175,10 @@ __device__ __forceinline__ uint4 f32x8_to_bf16(const float (&v)[8]) {
 // at all (the accumulators are kept live so that the main loop is not optimised away): cost-structure ablations, guide rule 17
 #ifndef DEMO_EPI_ABLATE
 #define DEMO_EPI_ABLATE 0
+#endif
+// phases per K-tile of the 256^2 kernels' main loops: 2 (32 MFMAs between barriers) or 4 (16, the round-1 form; A/B variant)
+#ifndef DEMO_PP_PHASES
+#define DEMO_PP_PHASES 2
 #endif
 __device__ __forceinline__ void st16(void* base, int64_t off, const u32x4 v) {
 #if DEMO_EPI_ABLATE == 1
@@ -752,11 +757,30 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
   // ntn tiles of each of their row panels -- the cold operand (activations, 76..304 MB) is then fetched once, and it is the
   // hot one (the weight matrix, <= 5 MB, L2 / Infinity-Cache resident) that gets re-read
   const int group_m = p.group_m;
-  const int per_group = group_m * p.ntn;
-  const int grp = tid / per_group, in_grp = tid - grp * per_group;
-  const int gm0 = grp * group_m;
-  const int gsz = (p.ntm - gm0) < group_m ? (p.ntm - gm0) : group_m;
-  const int m0 = (gm0 + in_grp % gsz) * BM, n0 = (in_grp / gsz) * BN;
+  int m0, n0;
+  if (p.colslice > 1) {
+    // Column-sliced order: XCD x keeps to weight panels [slice * c, (slice + 1) * c) (slice = x % S, c = ntn / S) for the whole launch
+    // and walks its share (one of 8 / S) of the row panels against them.  The slice (c * 393 KB at K = 768) then stays in the XCD's
+    // 4-MB L2 from one round of tiles to the next, where the whole matrix (3.5 .. 4.7 MB) plus the streaming activations does not.
+    const int S = p.colslice, R = 8 / S, c = p.ntn / S;
+    const int j = bid >> 3, slice = xcd % S, rs = xcd / S;
+    const int rbase = p.ntm / R, rrem = p.ntm - rbase * R;
+    const int rows = rbase + (rs < rrem ? 1 : 0), row0 = rs * rbase + (rs < rrem ? rs : rrem);
+    if (j >= rows * c) return;                       // (the grid is 8 x the largest share)
+    const int per_group = group_m * c;
+    const int grp = j / per_group, in_grp = j - grp * per_group;
+    const int gm0 = grp * group_m;
+    const int gsz = (rows - gm0) < group_m ? (rows - gm0) : group_m;
+    m0 = (row0 + gm0 + in_grp % gsz) * BM;
+    n0 = (slice * c + in_grp / gsz) * BN;
+  } else {
+    const int per_group = group_m * p.ntn;
+    const int grp = tid / per_group, in_grp = tid - grp * per_group;
+    const int gm0 = grp * group_m;
+    const int gsz = (p.ntm - gm0) < group_m ? (p.ntm - gm0) : group_m;
+    m0 = (gm0 + in_grp % gsz) * BM;
+    n0 = (in_grp / gsz) * BN;
+  }
   const int z = blockIdx.y;
   const bf16_t* A = p.A + z * p.sA;
   const bf16_t* B = p.B + z * p.sB;
@@ -807,6 +831,67 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
     __builtin_amdgcn_s_barrier();                                                                                \
   } while (0)
 
+#if DEMO_PP_PHASES == 2
+  // TWO phases per K-tile (32 MFMAs each: one 64-row half of the wave's C against all four column tiles) instead of four of 16:
+  // the same fragment registers (a: 32, b: 32), half the barriers, and a hand-over of the MFMA pipe between the two wave halves
+  // every 512 instead of every 256 MFMA clocks.
+  //   P1: read b0, b1 (4 col tiles x 2 k-halves), a0 (4 row tiles x 2)   stage B(t+1)    MFMA acc[0..3][0..3]
+  //   P2: read a1 (over a0's registers)                                   stage A(t+2)    MFMA acc[4..7][0..3]
+  // K-tile t+1 must have landed before GLOBAL barrier 4t+3 (the first barrier whose far side reads it: P1(t+1) of the leading
+  // half): the leading half waits for its own pieces after the MFMAs of P2, before its closing barrier; the trailing half, one
+  // barrier behind, before the FIRST barrier of its P2 -- the same global barrier.  B(t+1) has had a whole K-tile to land
+  // (three quarters of one for the trailing half).  Re-staging: B slot t&1 was last read at P1(t-1) (waited for before global
+  // barrier 4t-2), A slot of t-1 at P2(t-1) (before global barrier 4t); the stagings follow global barriers 4t-1 and 4t+1.
+#define PP_MFMA32(I0)                                                                                            \
+  do {                                                                                                           \
+    __builtin_amdgcn_s_barrier();                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                                               \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                             \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
+          acc[I0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0f[kk][j], af[kk][i], acc[I0 + i][j], 0, 0, 0); \
+          acc[I0 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[kk][j], af[kk][i], acc[I0 + i][2 + j], 0, 0, 0); \
+        }                                                                                                        \
+    __builtin_amdgcn_s_setprio(0);                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+  } while (0)
+  int sa = 0;                                       // A ring slot of tile t
+  for (int t = 0; t < nk; ++t) {
+    const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
+    const int sa2 = sa == 0 ? 2 : sa - 1;           // slot of tile t+2 == slot of tile t-1
+    const unsigned la = lds_off(smem + sa * A_BYTES + wr * (128 * 128));
+    const unsigned lb = lds_off(smem_b + ((t + 1) & 1) * B_BYTES + wc * (64 * 128));      // B(t) sits in slot (t+1)&1
+    bf16x8 af[2][4], b0f[2][2], b1f[2][2];
+    // ---- P1
+    lds_read2(b0f[0], lb + foff0);
+    lds_read2(b0f[1], lb + foff1);
+    lds_read2(b1f[0], lb + 4096 + foff0);
+    lds_read2(b1f[1], lb + 4096 + foff1);
+    lds_read4(af[0], la + foff0);
+    lds_read4(af[1], la + foff1);
+    if (has1) stage_tile<BN, NW, REG_EPI>(B, p.ldb, n0, p.N, (t + 1) * BK, smem_b + (t & 1) * B_BYTES, wave, lane);
+    PP_MFMA32(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- P2
+    lds_read4(af[0], la + 8192 + foff0);
+    lds_read4(af[1], la + 8192 + foff1);
+    if (has2) stage_tile<BM, NW, false, DEMO_A_AUX>(A, p.lda, m0, p.M, (t + 2) * BK, smem + sa2 * A_BYTES, wave, lane);
+    if (wr == 1) {
+      if (has2) wait_vmcnt<4>();
+      else if (has1) wait_vmcnt<0>();
+    }
+    PP_MFMA32(4);
+    if (wr == 0) {
+      if (has2) wait_vmcnt<4>();
+      else if (has1) wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    sa = sa == 2 ? 0 : sa + 1;
+  }
+#undef PP_MFMA32
+#else
   int sa = 0;                                       // A ring slot of tile t
   for (int t = 0; t < nk; ++t) {
     const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
@@ -837,6 +922,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
     PP_MFMA(af, b0f, 4, 0);
     sa = sa == 2 ? 0 : sa + 1;
   }
+#endif
 #undef PP_MFMA
   if (wr == 0) __builtin_amdgcn_s_barrier();      // re-join the halves: every ds_read of this output tile is done
 
@@ -1040,6 +1126,8 @@ static int g_pp_reg_epi = 1;   // 256^2 kernel: 1 = register epilogue over permu
 static int g_pp_min_eff_pct = 70;
 static int g_dephase = 0;
 extern "C" int demo_gemm_set_dephase(int units) { g_dephase = units < 0 ? 0 : units; return 0; }
+static int g_colslice = 0;     // 0 = heuristic, 1 = off, 2 / 4 / 8 = forced where ntn divides
+extern "C" int demo_gemm_set_colslice(int s) { g_colslice = s; return 0; }
 extern "C" int demo_gemm_store_policy(void) { return DEMO_STORE_POL; }
 extern "C" int demo_gemm_set_pp_min_fill(int pct) { g_pp_min_eff_pct = pct; return 0; }
 void demo_gemm_tn_force(int t);
@@ -1127,6 +1215,7 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
   p.pre_out_kind = d.pre_out ? d.pre_out_kind : 0;
   p.dtRes = d.residual ? d.dtRes : 0;
   p.dephase = g_dephase;
+  p.colslice = 0;
   p.M = d.M; p.N = d.N; p.K = d.K;
   p.lda = d.a_rs; p.ldb = d.b_rs; p.ldc = d.c_rs;
   const bool lvl1 = d.batch1 != 1;
@@ -1160,10 +1249,21 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
       p.ntm = (int)cdiv64(d.M, 256);
       p.ntn = d.N / 256;
       p.group_m = 32 / p.ntn < 1 ? 1 : (32 / p.ntn > 8 ? 8 : 32 / p.ntn);      // (2..8 measured within 1 % of each other)
-      if (g_pp_reg_epi)
-        hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<true>, dim3((unsigned)(p.ntm * p.ntn), (unsigned)nb), dim3(512), 0, s, p);
-      else
-        hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<false>, dim3((unsigned)(p.ntm * p.ntn), (unsigned)nb), dim3(512), 0, s, p);
+      {
+        unsigned grid = (unsigned)(p.ntm * p.ntn);
+        p.colslice = 0;
+        const int S = g_colslice;
+        if (S > 1 && 8 % S == 0 && p.ntn % S == 0 && nb == 1) {
+          const int c = p.ntn / S, R = 8 / S;
+          p.colslice = S;
+          p.group_m = 32 / c < 1 ? 1 : (32 / c > 8 ? 8 : 32 / c);
+          grid = 8u * (unsigned)(cdiv64(p.ntm, R) * c);
+        }
+        if (g_pp_reg_epi)
+          hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<true>, dim3(grid, (unsigned)nb), dim3(512), 0, s, p);
+        else
+          hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<false>, dim3(grid, (unsigned)nb), dim3(512), 0, s, p);
+      }
       break;
     case 2576:                                       // 256 x 128 twin kernel (two workgroups per CU)
       p.ntm = (int)cdiv64(d.M, 256);

@@ -208,6 +208,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const TArgs p) {
 // Hazards: stage t+1 is waited for (counted vmcnt: stages t+2, t+3 stay in flight) before the first barrier of phase 2 of
 // stage t and first read two barriers later; slot (t+3)%5 is re-filled at phase 1 of stage t, its last reader was phase 2
 // of stage t-2.  512-B rows: the bank of a 16-B chunk depends on chunk&15 only, so the swizzle of the 128^2 form carries over.
+#ifndef DEMO_PP_PHASES
+#define DEMO_PP_PHASES 2      // 32 MFMAs between barriers (see gemm_bf16.hip); 4 = the round-1 form with 16
+#endif
 constexpr int PBM = 256, PBN = 256, PBK = 32, PSTAGES = 5;
 constexpr int POP_BYTES = PBK * 512;          // 16 KiB per operand per stage
 constexpr int PSTAGE_BYTES = 2 * POP_BYTES;
@@ -329,6 +332,49 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_pp_kernel(const TArgs p) 
   for (int t = 0; t < nk; ++t) {
     const unsigned cur = lds_base + slot * PSTAGE_BYTES;
     slot = slot + 1 == PSTAGES ? 0 : slot + 1;
+#if DEMO_PP_PHASES == 2
+    // ONE phase per stage: all 8 x 4 MFMA tiles of the wave (32 MFMAs) between two barriers -- 48 fragment registers instead of 32,
+    // half the barriers and half the hand-overs of the MFMA pipe between the wave halves.  Stage t+1 must have landed before GLOBAL
+    // barrier 2t+1 (its first reader, the leading half, is on the far side): the leading half waits for its pieces after its MFMAs,
+    // before the closing barrier; the trailing half, one barrier behind, before its first barrier -- the same global barrier.
+    s16x4 araw[8][2], braw[4][2];
+    bf16x8 af[8], bfr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pp_tr_read(braw[j], cur + boff[j]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pp_tr_read(araw[i], cur + aoff[i]);
+    if (t + 3 < nk) stage(t + 3);
+    if (wr == 1) {
+      if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = pp_join(braw[j]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = pp_join(araw[i]);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    if constexpr (CS) {
+      // bias gradient, branch-free: wave wc sums output row tile wc of each 64-row half = fragments 0 and 4 (rotated order)
+      csum[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], ones, csum[0], 0, 0, 0);
+      csum[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[4], ones, csum[1], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 0) {
+      if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+#else
     s16x4 araw[4][2], braw[4][2];
     bf16x8 af[4], bfr[4];
     // ---- phase 1: output rows 0..63 of the wave
@@ -379,6 +425,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_pp_kernel(const TArgs p) 
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+  #endif
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();        // re-join the halves
 
