@@ -40,6 +40,7 @@ struct FArgs {
   int ntm, ntn;
   int group_m;                 // 256^2 kernel: row panels per tile-order group
   int dephase;                 // 256^2 kernel, tuning hook: first-round workgroups start ((id >> 3) & 3) * dephase * 64 clocks late
+  int epi_stage;               // 256^2 kernel, register epilogue: bf16 outputs leave through an LDS image of the tile (whole-row stores)
   int colslice;                // 256^2 kernel: > 1 = every XCD keeps to ntn / colslice weight panels for the whole launch (see the kernel)
 };
 
@@ -198,8 +199,9 @@ __device__ __forceinline__ u32x4 as_u32x4(float a, float b, float c, float d) {
   return (u32x4){__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
 }
 
+// v: in = alpha * accumulator, out = the 8 values of C; s: the 8 values of the second output (pre-activation or act'), valid iff p.pre_out
 template <int ACT, int GK>
-__device__ __forceinline__ void epi8_finish(const FArgs& p, const float4 bz0, const float4 bz1, const EpiOps& x, int64_t ci, float (&v)[8]) {
+__device__ __forceinline__ void epi8_compute(const FArgs& p, const float4 bz0, const float4 bz1, const EpiOps& x, float (&v)[8], float (&s)[8]) {
   const int act = ACT >= 0 ? ACT : p.act;
   const int gk = GK >= 0 ? GK : p.act_grad_kind;
   const bool has_pre = GK >= 0 ? GK != DEMO_ACT_NONE : p.pre != nullptr;
@@ -207,19 +209,12 @@ __device__ __forceinline__ void epi8_finish(const FArgs& p, const float4 bz0, co
   v[4] += bz1.x; v[5] += bz1.y; v[6] += bz1.z; v[7] += bz1.w;
   const bool save_deriv = p.pre_out && p.pre_out_kind == 1;
   if (p.pre_out) {
-    float s[8];
     if (save_deriv) {                                      // activation and its derivative from one exp / rcp (or erf) per element
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = act_both(v[e], act, s[e]);
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) s[e] = v[e];
-    }
-    if (p.dtC == DEMO_F32) {
-      st16(p.pre_out, ci * 4, as_u32x4(s[0], s[1], s[2], s[3]));
-      st16(p.pre_out, ci * 4 + 16, as_u32x4(s[4], s[5], s[6], s[7]));
-    } else {
-      st16(p.pre_out, ci * 2, as_u32x4(f32x8_to_bf16(s)));
     }
   }
   if (act != DEMO_ACT_NONE && !save_deriv) {
@@ -235,12 +230,24 @@ __device__ __forceinline__ void epi8_finish(const FArgs& p, const float4 bz0, co
     v[0] += x.res0.x; v[1] += x.res0.y; v[2] += x.res0.z; v[3] += x.res0.w;
     v[4] += x.res1.x; v[5] += x.res1.y; v[6] += x.res1.z; v[7] += x.res1.w;
   }
-  if (p.dtC == DEMO_F32) {
-    float* c = reinterpret_cast<float*>(p.C) + ci;
-    if (p.accumulate) {
-      v[0] += x.old0.x; v[1] += x.old0.y; v[2] += x.old0.z; v[3] += x.old0.w;
-      v[4] += x.old1.x; v[5] += x.old1.y; v[6] += x.old1.z; v[7] += x.old1.w;
+  if (p.dtC == DEMO_F32 && p.accumulate) {
+    v[0] += x.old0.x; v[1] += x.old0.y; v[2] += x.old0.z; v[3] += x.old0.w;
+    v[4] += x.old1.x; v[5] += x.old1.y; v[6] += x.old1.z; v[7] += x.old1.w;
+  }
+}
+template <int ACT, int GK>
+__device__ __forceinline__ void epi8_finish(const FArgs& p, const float4 bz0, const float4 bz1, const EpiOps& x, int64_t ci, float (&v)[8]) {
+  float s[8];
+  epi8_compute<ACT, GK>(p, bz0, bz1, x, v, s);
+  if (p.pre_out) {
+    if (p.dtC == DEMO_F32) {
+      st16(p.pre_out, ci * 4, as_u32x4(s[0], s[1], s[2], s[3]));
+      st16(p.pre_out, ci * 4 + 16, as_u32x4(s[4], s[5], s[6], s[7]));
+    } else {
+      st16(p.pre_out, ci * 2, as_u32x4(f32x8_to_bf16(s)));
     }
+  }
+  if (p.dtC == DEMO_F32) {
     st16(p.C, ci * 4, as_u32x4(v[0], v[1], v[2], v[3]));
     st16(p.C, ci * 4 + 16, as_u32x4(v[4], v[5], v[6], v[7]));
   } else {
@@ -364,8 +371,39 @@ __device__ __forceinline__ void epi_rows(const FArgs& p, const float* __restrict
 // group requested first.
 // LOADS: which global operands besides the bias the epilogue reads, as a compile-time mask (1 fp32 residual, 5 = 1 | 4 bf16 residual, 2 act'(pre) source in bf16,
 // 0 none) or -1 = decided at run time (any combination, G = 1: every unit then budgets all 24 operand registers).
-template <int G, int ACT, int GK, int LOADS>
-__device__ __forceinline__ void pp_epi_k(const FArgs& p, const f32x4 (&acc)[8][4], int mrow, int ncol, int64_t coff, const float* bias) {
+// SINK 1 (bf16 outputs only): the finished values do not leave in the accumulator layout (16 rows x 64 B per store instruction: a
+// CU's store path moves ~10 B/clk that way, tools/probes/store_probe.hip) but through an LDS image of the output tile -- 256 rows x
+// 512 B over the main loop's ring, 16-B chunk index XOR (row & 31) -- from which every wave drains 32 whole rows, two per store
+// instruction (~20 B/clk per CU).  SINK 2 (two outputs: fc1 forward) works the tile in two 128-row halves, each with a 64-KB image per output.
+__device__ __forceinline__ unsigned pp_tile_slot(int row, int chunk) { return (unsigned)(row * 512 + ((chunk ^ (row & 31)) << 4)); }
+__device__ __forceinline__ void pp_drain(const FArgs& p, void* out, const char* lds, int m0, int n0, int64_t coff, int wave, int lane) {
+  u32x4 r[16];
+  const int rsub = lane >> 5, chunk = lane & 31;
+#pragma unroll
+  for (int it = 0; it < 16; ++it) r[it] = *reinterpret_cast<const u32x4*>(lds + pp_tile_slot(wave * 32 + it * 2 + rsub, chunk));
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int m = m0 + wave * 32 + it * 2 + rsub;
+    if (m < p.M) st16(out, (coff + (int64_t)m * p.ldc + n0 + chunk * 8) * 2, r[it]);
+  }
+}
+// half images of SINK 2: 128 image rows = the 64-row half `half` of both wave rows; 16 image rows per wave
+__device__ __forceinline__ void pp_drain_half(const FArgs& p, void* out, const char* img, int m0, int n0, int64_t coff, int half, int wave,
+                                              int lane) {
+  u32x4 r[8];
+  const int rsub = lane >> 5, chunk = lane & 31;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) r[it] = *reinterpret_cast<const u32x4*>(img + pp_tile_slot(wave * 16 + it * 2 + rsub, chunk));
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int hr = wave * 16 + it * 2 + rsub;
+    const int m = m0 + (hr >> 6) * 128 + half * 64 + (hr & 63);
+    if (m < p.M) st16(out, (coff + (int64_t)m * p.ldc + n0 + chunk * 8) * 2, r[it]);
+  }
+}
+template <int G, int ACT, int GK, int LOADS, int SINK = 0>
+__device__ __forceinline__ void pp_epi_k(const FArgs& p, const f32x4 (&acc)[8][4], int mrow, int ncol, int64_t coff, const float* bias,
+                                         char* lds = nullptr, int m0 = 0, int n0 = 0) {
   const bool has_pre = LOADS >= 0 ? (LOADS & 2) != 0 : (GK >= 0 ? GK != DEMO_ACT_NONE : p.pre != nullptr);
   const bool has_res = LOADS >= 0 ? (LOADS & 1) != 0 : p.residual != nullptr;
   const bool has_old = LOADS >= 0 ? false : (p.accumulate && p.dtC == DEMO_F32);
@@ -449,19 +487,64 @@ __device__ __forceinline__ void pp_epi_k(const FArgs& p, const f32x4 (&acc)[8][4
     }
 #pragma unroll
     for (int u = 0; u < G; ++u) {
-      if (!ok[u]) continue;
+      if (SINK == 0 && !ok[u]) continue;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const f32x4 a = acc[i0 + u][2 * h], b = acc[i0 + u][2 * h + 1];
         float v[8] = {a[0] * p.alpha, a[1] * p.alpha, a[2] * p.alpha, a[3] * p.alpha, b[0] * p.alpha, b[1] * p.alpha, b[2] * p.alpha, b[3] * p.alpha};
-        epi8_finish<ACT, GK>(p, bz[h][0], bz[h][1], x[u][h], ci[u][h], v);
+        if constexpr (SINK == 0) {
+          epi8_finish<ACT, GK>(p, bz[h][0], bz[h][1], x[u][h], ci[u][h], v);
+        } else {
+          float sv[8];
+          epi8_compute<ACT, GK>(p, bz[h][0], bz[h][1], x[u][h], v, sv);
+          const int ch = ((ncol - n0) >> 3) + h * 4;
+          if constexpr (SINK == 1) {
+            *reinterpret_cast<u32x4*>(lds + pp_tile_slot(mrow - m0 + (i0 + u) * 16, ch)) = as_u32x4(f32x8_to_bf16(v));
+          } else {                                   // two 128-row half images (C, second output): image row = wr * 64 + (i & 3) * 16 + frow
+            const int hr = (mrow - m0) - ((mrow - m0) >> 7) * 64 + ((i0 + u) & 3) * 16;
+            *reinterpret_cast<u32x4*>(lds + pp_tile_slot(hr, ch)) = as_u32x4(f32x8_to_bf16(v));
+            *reinterpret_cast<u32x4*>(lds + 65536 + pp_tile_slot(hr, ch)) = as_u32x4(f32x8_to_bf16(sv));
+          }
+        }
+      }
+    }
+    if constexpr (SINK == 2) {                       // (G = 1) the wave's row tiles 0..3, then 4..7: drain both half images
+      if (i0 + G == 4 || i0 + G == 8) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        __syncthreads();
+        pp_drain_half(p, p.C, lds, m0, n0, coff, (i0 + G) / 4 - 1, wave, lane);
+        pp_drain_half(p, p.pre_out, lds + 65536, m0, n0, coff, (i0 + G) / 4 - 1, wave, lane);
+        if (i0 + G == 4) __syncthreads();
       }
     }
   }
+  if constexpr (SINK == 1) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    pp_drain(p, p.C, lds, m0, n0, coff, wave, lane);
+  }
 }
-__device__ __forceinline__ void pp_epi(const FArgs& p, const f32x4 (&acc)[8][4], int mrow, int ncol, int64_t coff, const float* bias) {
+__device__ __forceinline__ void pp_epi(const FArgs& p, const f32x4 (&acc)[8][4], int mrow, int ncol, int64_t coff, const float* bias,
+                                       char* lds = nullptr, int m0 = 0, int n0 = 0) {
   const int gk = p.pre ? p.act_grad_kind : DEMO_ACT_NONE;
   const bool old = p.accumulate && p.dtC == DEMO_F32;
+  if (lds && p.epi_stage && p.dtC == DEMO_BF16) {                   // whole-row stores through an LDS image of the tile (bf16 outputs)
+    if (!p.pre && !p.residual) {
+      if (p.pre_out) {                                       // fc1 forward: two outputs (pre-activation or act')
+        if (p.act == DEMO_ACT_QUICKGELU) { pp_epi_k<1, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE, 0, 2>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
+        if (p.act == DEMO_ACT_GELU) { pp_epi_k<1, DEMO_ACT_GELU, DEMO_ACT_NONE, 0, 2>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
+      } else {
+        if (p.act == DEMO_ACT_NONE) { pp_epi_k<1, DEMO_ACT_NONE, DEMO_ACT_NONE, 0, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
+        if (p.act == DEMO_ACT_QUICKGELU) { pp_epi_k<1, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE, 0, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
+      }
+    } else if (p.residual && p.dtRes == DEMO_BF16 && !p.pre && !p.pre_out && p.act == DEMO_ACT_NONE) {
+      pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_NONE, 5, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0);
+      return;
+    } else if (p.pre && p.dtPre == DEMO_BF16 && !p.residual && !p.pre_out && p.act == DEMO_ACT_NONE) {
+      if (gk == DEMO_ACT_SAVED) { pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_SAVED, 2, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
+      if (gk == DEMO_ACT_QUICKGELU) { pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_QUICKGELU, 2, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
+    }
+  }
   if (!p.pre && !p.residual && !old) {                       // nothing to read but the bias: trunk qkv / fc1 forward, plain dX products
     if (p.act == DEMO_ACT_NONE) pp_epi_k<1, DEMO_ACT_NONE, DEMO_ACT_NONE, 0>(p, acc, mrow, ncol, coff, bias);
     else if (p.act == DEMO_ACT_QUICKGELU) pp_epi_k<1, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE, 0>(p, acc, mrow, ncol, coff, bias);
@@ -940,7 +1023,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-    pp_epi(p, acc, m0 + wr * 128 + frow, n0 + wc * 64 + g4 * 8, coff, bias);
+    pp_epi(p, acc, m0 + wr * 128 + frow, n0 + wc * 64 + g4 * 8, coff, bias, smem, m0, n0);
 #endif
     return;
   }
@@ -1126,6 +1209,8 @@ static int g_pp_reg_epi = 1;   // 256^2 kernel: 1 = register epilogue over permu
 static int g_pp_min_eff_pct = 70;
 static int g_dephase = 0;
 extern "C" int demo_gemm_set_dephase(int units) { g_dephase = units < 0 ? 0 : units; return 0; }
+static int g_epi_stage = 1;
+extern "C" int demo_gemm_set_epi_stage(int on) { g_epi_stage = on ? 1 : 0; return 0; }
 static int g_colslice = 0;     // 0 = heuristic, 1 = off, 2 / 4 / 8 = forced where ntn divides
 extern "C" int demo_gemm_set_colslice(int s) { g_colslice = s; return 0; }
 extern "C" int demo_gemm_store_policy(void) { return DEMO_STORE_POL; }
@@ -1216,6 +1301,7 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
   p.dtRes = d.residual ? d.dtRes : 0;
   p.dephase = g_dephase;
   p.colslice = 0;
+  p.epi_stage = g_epi_stage;
   p.M = d.M; p.N = d.N; p.K = d.K;
   p.lda = d.a_rs; p.ldb = d.b_rs; p.ldc = d.c_rs;
   const bool lvl1 = d.batch1 != 1;
