@@ -394,6 +394,125 @@ __global__ __launch_bounds__(256) void layernorm_fwd_lp8_kernel(const bf16_t* __
   }
 }
 
+// LayerNorm backward on all-bf16 streams, HALF a wave per row (as the forward above): a lane owns the 8-column chunks lane32 + 32 i of
+// its row (16-B accesses; D = 768: three), the row sums are two half-wave DPP reductions -- no LDS, no barrier inside the row loop
+// (the 128-thread form above spends a workgroup barrier per four rows and leaves 32 of its 128 lanes idle at D = 768) -- and the next
+// row of all three operands is requested before the current one is worked.  Column sums (dw, db) stay in registers over the
+// workgroup's rows and are combined once at the end (half-waves by shuffle, waves through LDS) into one partial row per workgroup.
+template <int NC>
+__global__ __launch_bounds__(256, 2) void layernorm_bwd_hw_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                  const float* __restrict__ w, const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
+                                                                  bf16_t* __restrict__ out, float* __restrict__ dw, float* __restrict__ db,
+                                                                  float* __restrict__ part, int M, int D, int rows_per_block) {
+  __shared__ float red[4][2][NC * 256];
+  const int l32 = threadIdx.x & 31, hw = threadIdx.x >> 5, wave = threadIdx.x >> 6;
+  const int nch = D >> 3;
+  float wv[NC][8], adw[NC][8], adb[NC][8];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = l32 + 32 * i;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 a = c < nch ? *reinterpret_cast<const float4*>(w + c * 8) : z, b = c < nch ? *reinterpret_cast<const float4*>(w + c * 8 + 4) : z;
+    wv[i][0] = a.x; wv[i][1] = a.y; wv[i][2] = a.z; wv[i][3] = a.w; wv[i][4] = b.x; wv[i][5] = b.y; wv[i][6] = b.z; wv[i][7] = b.w;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) adw[i][e] = adb[i][e] = 0.f;
+  }
+  const float inv_d = 1.f / (float)D;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int rend = min(M, r0 + rows_per_block);
+  const int iters = (rend - r0 + 7) >> 3;            // workgroup-uniform: every half-wave runs every iteration (rows past the end masked)
+  const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+  uint4 xn[NC], dn[NC], pn[NC];
+  float mun = 0.f, rsn = 0.f;
+  auto fetch = [&](int row) {
+    const bool rowok = row < rend;
+    const int64_t o = (int64_t)(rowok ? row : r0) * D;
+    mun = mean[rowok ? row : r0];
+    rsn = rowok ? rstd[row] : 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = l32 + 32 * i;
+      const bool ok = rowok && c < nch;
+      xn[i] = ok ? *reinterpret_cast<const uint4*>(x + o + c * 8) : z4;
+      dn[i] = ok ? *reinterpret_cast<const uint4*>(dy + o + c * 8) : z4;
+      pn[i] = (ok && dres) ? *reinterpret_cast<const uint4*>(dres + o + c * 8) : z4;
+    }
+  };
+  fetch(r0 + hw);
+  for (int it = 0; it < iters; ++it) {
+    const int row = r0 + hw + it * 8;
+    uint4 xr[NC], dr[NC], pr[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) { xr[i] = xn[i]; dr[i] = dn[i]; pr[i] = pn[i]; }
+    const float mu = mun, rs = rsn;
+    if (it + 1 < iters) fetch(row + 8);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      float xf[8], df[8];
+      bf16x8_unpack(xr[i], xf);
+      bf16x8_unpack(dr[i], df);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float g = df[e] * wv[i][e];
+        s1 += g;
+        s2 = fmaf(g, (xf[e] - mu) * rs, s2);
+      }
+    }
+    s1 = half_wave_sum(s1) * inv_d;
+    s2 = half_wave_sum(s2) * inv_d;
+    const bool rowok = row < rend;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      float xf[8], df[8], pf[8], o[8];
+      bf16x8_unpack(xr[i], xf);
+      bf16x8_unpack(dr[i], df);
+      bf16x8_unpack(pr[i], pf);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (xf[e] - mu) * rs;           // (masked rows: dy = 0 and rstd = 0, so nothing is added)
+        adw[i][e] = fmaf(df[e], xh, adw[i][e]);
+        adb[i][e] += df[e];
+        o[e] = pf[e] + rs * (df[e] * wv[i][e] - s1 - xh * s2);
+      }
+      const int c = l32 + 32 * i;
+      if (rowok && c < nch) {
+        uint4 q;
+        q.x = pack_bf16x2(o[0], o[1]); q.y = pack_bf16x2(o[2], o[3]); q.z = pack_bf16x2(o[4], o[5]); q.w = pack_bf16x2(o[6], o[7]);
+        *reinterpret_cast<uint4*>(out + (int64_t)row * D + c * 8) = q;
+      }
+    }
+  }
+  if (!dw && !db) return;
+  // column sums: the two half-waves of a wave own the same columns
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      adw[i][e] += __shfl_xor(adw[i][e], 32, 64);
+      adb[i][e] += __shfl_xor(adb[i][e], 32, 64);
+    }
+  if ((threadIdx.x & 63) < 32) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = l32 + 32 * i;
+      *reinterpret_cast<float4*>(&red[wave][0][c * 8]) = make_float4(adw[i][0], adw[i][1], adw[i][2], adw[i][3]);
+      *reinterpret_cast<float4*>(&red[wave][0][c * 8 + 4]) = make_float4(adw[i][4], adw[i][5], adw[i][6], adw[i][7]);
+      *reinterpret_cast<float4*>(&red[wave][1][c * 8]) = make_float4(adb[i][0], adb[i][1], adb[i][2], adb[i][3]);
+      *reinterpret_cast<float4*>(&red[wave][1][c * 8 + 4]) = make_float4(adb[i][4], adb[i][5], adb[i][6], adb[i][7]);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * D; c += 256) {
+    const int k = c >= D ? 1 : 0, col = c - k * D;
+    const float v = (red[0][k][col] + red[1][k][col]) + (red[2][k][col] + red[3][k][col]);
+    if (part) part[(int64_t)blockIdx.x * 2 * D + c] = v;
+    else if (k == 0) { if (dw) atomicAdd(&dw[col], v); }
+    else if (db) atomicAdd(&db[col], v);
+  }
+}
+
 // Backward, row-owner form (any D up to 2048): one wave per row for dx; dw/db accumulated per block in LDS then atomically
 // added into fp32 dw/db (D floats each; D*gridDim atomics spread over D addresses).
 // NV = float4 per lane (compile time: D = 768 -> 3), so that only the registers a row needs are allocated and 8 waves per
@@ -660,8 +779,8 @@ extern "C" int demo_layernorm_fwd(const float* x, const float* w, const float* b
   return 0;
 }
 
-static int g_ln_lp8 = 1;      // tuning hook: 0 = the wave-per-row / 4-column kernels also for all-bf16 streams
-extern "C" int demo_layernorm_set_lp8(int on) { g_ln_lp8 = on != 0; return 0; }
+static int g_ln_lp8 = 1;      // tuning hook: 0 = the wave-per-row / 4-column kernels also for all-bf16 streams, 2 = backward in the 128-thread 8-column form
+extern "C" int demo_layernorm_set_lp8(int on) { g_ln_lp8 = on < 0 ? 0 : on; return 0; }
 
 extern "C" int demo_layernorm_add_fwd(const void* x, int32_t dtX, const void* add, int32_t dtAdd, void* xsum_out, const float* w, const float* b,
                                       float eps, void* y, int32_t dtY, float* mean, float* rstd, int32_t M, int32_t D, void* stream) {
@@ -752,14 +871,20 @@ extern "C" int demo_layernorm_bwd_lp(const void* dy, int32_t dtDy, const void* x
   DEMO_REQUIRE(D % 4 == 0 && D <= 1024, "demo_layernorm_bwd_lp: D=%d unsupported (<= 1024)", D);
   DEMO_REQUIRE(dy && x && w && mean && rstd && dx_bf16 && M > 0, "demo_layernorm_bwd_lp: null operand");
   hipStream_t s = (hipStream_t)stream;
-  const int rows_per_block = M >= 16384 ? 32 : 16;
+  const bool hw_form = dtDy == DEMO_BF16 && dtX == DEMO_BF16 && D % 8 == 0 && D <= 768 && g_ln_lp8 == 1;      // all-bf16 streams: half a wave per row
+  // half-wave form: two 256-thread workgroups fit a CU (238 VGPRs), so the grid is ONE round of 512 workgroups where M allows (774 workgroups
+  // of 64 rows ran as 1.5 rounds: the second half empty)
+  const int rows_per_block = hw_form ? (int)(cdiv64(M, 512) < 8 ? 8 : cdiv64(M, 512)) : (M >= 16384 ? 32 : 16);
   const int nblk = (int)cdiv64(M, rows_per_block);
   float* part = (workspace && workspace_elems >= (int64_t)nblk * 2 * D && (dw || db)) ? workspace : nullptr;
   const dim3 blk((unsigned)(cdiv64(D, 256) * 64));
 #define LN_LP(TDY_, TX_)                                                                                                               \
   hipLaunchKernelGGL((layernorm_bwd_cols_kernel<TDY_, 4, false, true, TX_>), dim3((unsigned)nblk), blk, 0, s, (const TDY_*)dy, (const TX_*)x, w, \
                      mean, rstd, (float*)nullptr, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block, (const bf16_t*)dres_bf16)
-  if (dtDy == DEMO_BF16 && dtX == DEMO_BF16 && D % 8 == 0 && g_ln_lp8)      // all-bf16 streams: 8 columns per thread, 16-B accesses
+  if (hw_form) {                                     // (wider rows spill at four chunks per lane: they keep the 128-thread form)
+    hipLaunchKernelGGL(layernorm_bwd_hw_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, w, mean, rstd,
+                       (const bf16_t*)dres_bf16, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block);
+  } else if (dtDy == DEMO_BF16 && dtX == DEMO_BF16 && D % 8 == 0 && g_ln_lp8)      // (hook value 2) the 128-thread form: 8 columns per thread
     hipLaunchKernelGGL(layernorm_bwd_lp8_kernel<4>, dim3((unsigned)nblk), dim3(128), 0, s, (const bf16_t*)dy, (const bf16_t*)x, w, mean, rstd,
                        (const bf16_t*)dres_bf16, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block);
   else if (dtDy == DEMO_BF16) { if (dtX == DEMO_BF16) LN_LP(bf16_t, bf16_t); else LN_LP(bf16_t, float); }

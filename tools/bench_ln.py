@@ -34,7 +34,8 @@ arms = [("fwd fp32 x -> bf16 (229 MB)", lambda: ops.layernorm_fwd(x32, w, b, 1e-
         ("fwd bf16 x -> bf16, half wave per row (152 MB)", lambda: (lib.demo_layernorm_set_lp8(1), ops.layernorm_add_fwd(x16, None, w, b, 1e-5, save=True)), 152e6),
         ("bwd lp, fp32 x, 4 cols (380 MB)", lambda: bwd(x32, 1), 380e6),
         ("bwd lp, bf16 x, 4 cols (304 MB)", lambda: bwd(x16, 0), 304e6),
-        ("bwd lp, bf16 x, 8 cols (304 MB)", lambda: bwd(x16, 1), 304e6)]
+        ("bwd lp, bf16 x, 8 cols, 128 threads (304 MB)", lambda: bwd(x16, 2), 304e6),
+        ("bwd lp, bf16 x, half wave per row (304 MB)", lambda: bwd(x16, 1), 304e6)]
 t = {n: [] for n, _, _ in arms}
 for _ in range(3):
     for n, f, _ in arms:
