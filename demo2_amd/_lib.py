@@ -102,7 +102,8 @@ PROTOTYPES = {
     "demo_hdm_vbias": [_P, _P, _L, _P, _I, _I, _I, _P],
     "demo_atmoe_gate_softmax": [_P, _P, _P, _I, _I, _I, _P],
     "demo_atmoe_eval_supported": [_I, _I],
-    "demo_atmoe_eval_fwd": [_P] * 15 + [_L, _L, _F] + [_P] * 5 + [_I, _I, _I, _P],
+    "demo_atmoe_eval_part_elems": [_I, _I],
+    "demo_atmoe_eval_fwd": [_P] * 14 + [_L, _L, _F] + [_P] * 5 + [_I, _I, _I, _P],
     "demo_xent_label_smooth": [_P, _L, _P, _I, _I, _F, _F, _P, _P, _L, _P, _P],
     "demo_triplet_soft_margin": [_P, _L, _P, _I, _I, _F, _P, _P, _L, _P, _P],
     "demo_triplet_loss": [_P, _L, _P, _I, _I, _F, _F, _P, _P, _L, _P, _P],
@@ -137,6 +138,7 @@ def load():
         fn.restype = C.c_int
     lib.demo_layernorm_bwd_workspace.restype = C.c_int64
     lib.demo_gemm_tn_workspace.restype = C.c_int64
+    lib.demo_atmoe_eval_part_elems.restype = C.c_int64
     lib.demo_last_error.argtypes = []
     lib.demo_last_error.restype = C.c_char_p
     if lib.demo_gemm_desc_size() != C.sizeof(GemmDesc):

@@ -377,11 +377,15 @@ def atmoe_forward(m, feats: Tensor, B: int, training: bool, tape: Optional[Tape]
         e1 = "generalFusion.moe.experts.0.expertHead.1.mlp."
         es = P.off(e1 + "0.weight") - P.off(e0 + "0.weight")
         ss = S.off(e1 + "2.running_mean") - S.off(e0 + "2.running_mean")
-        ws = m._ws.setdefault(("atmoe_eval", B), {})          # two alternating zeroed accumulators + the expert-output workspace
+        ws = m._ws.setdefault(("atmoe_eval", B), {})          # the three workspaces of this batch size
+        gfold = m.weight_cache("atmoe_gfold", torch.float32)  # Wq[h]^T Wk[h]: weights only, once per parameter version
+        if gfold is None:
+            gfold = ops.atmoe_fold_keys(P.f(gk + "q_.weight"), P.f(gk + "k_.weight"), H)
+            m.weight_cache_put("atmoe_gfold", torch.float32, gfold)
         bn1 = (P.f(gk + "linear_re.2.weight"), P.f(gk + "linear_re.2.bias"), S.f(gk + "linear_re.2.running_mean"),
                S.f(gk + "linear_re.2.running_var"))
-        return ops.atmoe_eval_fwd(feats, P.f(gk + "linear_re.0.weight"), P.f(gk + "linear_re.0.bias"), bn1, P.f(gk + "q_.weight"),
-                                  P.f(gk + "k_.weight"), P.f(e0 + "0.weight"), P.f(e0 + "0.bias"), P.f(e0 + "2.weight"), P.f(e0 + "2.bias"),
+        return ops.atmoe_eval_fwd(feats, P.f(gk + "linear_re.0.weight"), P.f(gk + "linear_re.0.bias"), bn1, gfold,
+                                  P.f(e0 + "0.weight"), P.f(e0 + "0.bias"), P.f(e0 + "2.weight"), P.f(e0 + "2.bias"),
                                   S.f(e0 + "2.running_mean"), S.f(e0 + "2.running_var"), es, ss, g.bn_eps, B, C, H, ws=ws)
     # (B, 7C) x (7C, C): a skinny product with a long reduction -> runs split-K (linear epilogue), activation applied after
     x1_pre = ops.gemm(feats.view(B, 7 * C), P.f(gk + "linear_re.0.weight"), bias=P.f(gk + "linear_re.0.bias"))

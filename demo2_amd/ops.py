@@ -724,32 +724,43 @@ def atmoe_eval_supported(Cd: int, H: int) -> bool:
     return bool(_lib.load().demo_atmoe_eval_supported(int(Cd), int(H)))
 
 
-def atmoe_eval_fwd(feats: Tensor, w1: Tensor, b1: Tensor, bn1: tuple, wq: Tensor, wk: Tensor, ew: Tensor, eb: Tensor, ebn_w: Tensor,
+def atmoe_fold_keys(wq: Tensor, wk: Tensor, H: int, out: Optional[Tensor] = None) -> Tensor:
+    """gfold (H*C, C) = [Wq[h]^T Wk[h] for h < H] (Wq[h], Wk[h]: rows h*d..(h+1)*d of the gate's q_ / k_ weights): the weights-only
+    factor of the gate scores, x2 . (gfold_h f_j) = (Wq[h] x2) . (Wk[h] f_j).  H small products on the library's GEMM; the caller
+    caches the result per parameter version."""
+    C = wq.shape[0]
+    d = C // H
+    assert wq.shape == wk.shape == (C, C) and C % H == 0
+    out = torch.empty(H * C, C, device=wq.device, dtype=torch.float32) if out is None else out
+    for h in range(H):
+        gemm(wq[h * d:(h + 1) * d].t(), wk[h * d:(h + 1) * d].t(), out=out[h * C:(h + 1) * C])
+    return out
+
+
+def atmoe_eval_fwd(feats: Tensor, w1: Tensor, b1: Tensor, bn1: tuple, gfold: Tensor, ew: Tensor, eb: Tensor, ebn_w: Tensor,
                    ebn_b: Tensor, ebn_mean: Tensor, ebn_var: Tensor, expert_stride: int, stat_stride: int, eps: float, Bs: int, Cd: int,
                    H: int, ws: Optional[dict] = None, want_gates: bool = False):
     """ATMoE in eval mode, two launches (demo_atmoe_eval_fwd): feats (Bs,7,C) fp32 -> moe (Bs,7C) [, gates (Bs,H,7)].  bn1 = (weight,
-    bias, running_mean, running_var) of the gate's BatchNorm; e* tensors START at expert (0,0)'s parameter (views into the flat
-    buffers), consecutive experts `expert_stride` (parameters) / `stat_stride` (running statistics) floats apart.
-    ws: a dict the caller keeps between calls (two zero-initialised accumulator buffers used alternately -- the kernel zeroes the one
-    the next call will take -- and the expert-output workspace); None = allocate for this call."""
-    _req_cuda(feats, w1, b1, wq, wk, ew, eb, ebn_w, ebn_b, ebn_mean, ebn_var, *bn1)
+    bias, running_mean, running_var) of the gate's BatchNorm; gfold = atmoe_fold_keys(q_.weight, k_.weight, H); e* tensors START at
+    expert (0,0)'s parameter (views into the flat buffers), consecutive experts `expert_stride` (parameters) / `stat_stride` (running
+    statistics) floats apart.  ws: a dict the caller keeps between calls (the three workspaces); None = allocate for this call."""
+    _req_cuda(feats, w1, b1, gfold, ew, eb, ebn_w, ebn_b, ebn_mean, ebn_var, *bn1)
     assert feats.dtype == torch.float32 and feats.is_contiguous() and feats.numel() == Bs * 7 * Cd
+    assert gfold.dtype == torch.float32 and gfold.is_contiguous() and gfold.shape == (H * Cd, Cd)
     dev = feats.device
     if ws is None:
         ws = {}
-    if ws.get("B") != Bs or ws.get("C") != Cd or ws["acc"][0].device != dev:
+    if ws.get("B") != Bs or ws.get("C") != Cd or ws.get("H") != H or ws["y"].device != dev:
         ws.clear()
-        ws.update(B=Bs, C=Cd, turn=0, acc=[torch.zeros(Bs * 8 * Cd, device=dev), torch.zeros(Bs * 8 * Cd, device=dev)],
-                  y=torch.empty(Bs, 7 * Cd, device=dev))
-    cur, nxt = ws["acc"][ws["turn"]], ws["acc"][ws["turn"] ^ 1]
-    ws["turn"] ^= 1
+        ws.update(B=Bs, C=Cd, H=H, part=torch.empty(_lib.load().demo_atmoe_eval_part_elems(Bs, Cd), device=dev),
+                  tkey=torch.empty(7 * Bs, H * Cd, device=dev), y=torch.empty(Bs, 7 * Cd, device=dev))
     moe = torch.empty(Bs, 7 * Cd, device=dev, dtype=torch.float32)
     gates = torch.empty(Bs, H, 7, device=dev, dtype=torch.float32) if want_gates else None
     check(_lib.load().demo_atmoe_eval_fwd(feats.data_ptr(), w1.data_ptr(), b1.data_ptr(), bn1[0].data_ptr(), bn1[1].data_ptr(), bn1[2].data_ptr(),
-                                          bn1[3].data_ptr(), wq.data_ptr(), wk.data_ptr(), ew.data_ptr(), eb.data_ptr(), ebn_w.data_ptr(),
+                                          bn1[3].data_ptr(), gfold.data_ptr(), ew.data_ptr(), eb.data_ptr(), ebn_w.data_ptr(),
                                           ebn_b.data_ptr(), ebn_mean.data_ptr(), ebn_var.data_ptr(), int(expert_stride), int(stat_stride),
-                                          float(eps), cur.data_ptr(), nxt.data_ptr(), ws["y"].data_ptr(), moe.data_ptr(), _ptr(gates), Bs, Cd, H,
-                                          _stream()), "demo_atmoe_eval_fwd")
+                                          float(eps), ws["part"].data_ptr(), ws["tkey"].data_ptr(), ws["y"].data_ptr(), moe.data_ptr(),
+                                          _ptr(gates), Bs, Cd, H, _stream()), "demo_atmoe_eval_fwd")
     return (moe, gates) if want_gates else moe
 
 

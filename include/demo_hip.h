@@ -295,22 +295,25 @@ int demo_tokens_grad(const float* dtok, const float* dcls, int64_t cls_ld, const
                      void* out, int32_t dt, int32_t Bn, int32_t L, int32_t C, void* stream);
 
 /* ---- ATMoE at inference, fused (AttnMOE.py:50-68 gate, :24-47 experts, :85-121 MoM.forward) --------------------------------------
- * Eval mode only (every BatchNorm1d is the affine map of its running statistics): the whole module in TWO launches --
- * stage 1: independent LDS-staged tiles of 64 output columns x <= 256 of the reduction: the gate's linear_re.0 (raw sums) and the keys
- * k_j = Wk f_j are ADDED into acc (fp32 atomics: the 7C-long reduction is cut so that no workgroup streams more than 64 KB of weights),
- * the 7*H experts y_jh = BN(QuickGELU(W_hj f_j[h] + b_hj)) are finished in place; stage 2, per head and 16 samples:
- * x2 = BN(QuickGELU(x1 + b1)), q_h = Wq[h] x2, g_hj = softmax_j(q_h . k_jh / sqrt(d)), moe[b, j*C + h*d + n] = g_hj * y_jh[n].
+ * Eval mode only (every BatchNorm1d is the affine map of its running statistics): the whole module in TWO launches.
+ * The gate's score q_h . k_jh = (Wq[h] x2) . (Wk[h] f_j) is evaluated as x2 . (G_h f_j) with G_h = Wq[h]^T Wk[h] (C x C), a product
+ * of weights only: gfold = [G_0; ..; G_{H-1}] (H*C, C) is computed by the caller once per parameter version (two demo_gemm calls per
+ * head) -- the q projection, the one step that needs the finished x2, no longer exists.
+ * stage 1: independent LDS-staged tiles of 64 output columns x 32 rows: the gate's linear_re.0 as ceil(7C/256) partial sums (ws_part),
+ * the folded keys t_j = G f_j (ws_tkey, (7B, H*C)), the 7*H experts y_jh = BN(QuickGELU(W_hj f_j[h] + b_hj)) (ws_y, (B, 7C));
+ * stage 2, one workgroup per sample: x2 = BN(QuickGELU(sum of the partials + b1)), g_hj = softmax_j(x2 . t_j[h] / sqrt(d)),
+ * moe[b, j*C + h*d + n] = g_hj * y_jh[n].  No atomics; every workspace element is written before it is read, nothing needs clearing.
  * feats (B,7,C) fp32; weights are pointers into the flat parameter / statistics buffers: ew / eb / ebn_w / ebn_b address expert
  * (h=0, j=0), expert (h, j) sits (7h + j) * expert_stride floats further (stat_stride for the running mean / var).
- * acc_zeroed: B*8C floats {x1 (B,C) | k (B,7,C)}, ZERO on entry (caller-owned); acc_next (optional): a second such buffer that stage 2
- * zeroes for the next call -- alternating two buffers, the caller never needs a memset.  ws_y (B,7C) workspace; gates (B,H,7) optional.
- * demo_atmoe_eval_supported: 1 if (C, H) fits the kernels (d = C/H a multiple of 16, <= 128). */
+ * ws_part: demo_atmoe_eval_part_elems(B, C) floats; ws_tkey: 7*B*H*C; ws_y: B*7*C; gates (B,H,7) optional.
+ * demo_atmoe_eval_supported: 1 if (C, H) fits the kernels (C <= 1024, C % H == 0, (C/H) % 4 == 0, 7 H <= 128). */
 int demo_atmoe_eval_supported(int32_t C, int32_t H);
+int64_t demo_atmoe_eval_part_elems(int32_t B, int32_t C);
 int demo_atmoe_eval_fwd(const float* feats, const float* w1, const float* b1, const float* bn1_w, const float* bn1_b,
-                        const float* bn1_mean, const float* bn1_var, const float* wq, const float* wk, const float* ew,
-                        const float* eb, const float* ebn_w, const float* ebn_b, const float* ebn_mean, const float* ebn_var,
-                        int64_t expert_stride, int64_t stat_stride, float eps, float* acc_zeroed, float* acc_next, float* ws_y, float* moe,
-                        float* gates, int32_t B, int32_t C, int32_t H, void* stream);
+                        const float* bn1_mean, const float* bn1_var, const float* gfold, const float* ew, const float* eb,
+                        const float* ebn_w, const float* ebn_b, const float* ebn_mean, const float* ebn_var, int64_t expert_stride,
+                        int64_t stat_stride, float eps, float* ws_part, float* ws_tkey, float* ws_y, float* moe, float* gates,
+                        int32_t B, int32_t C, int32_t H, void* stream);
 
 /* ---- training losses: value and gradient in one launch -----------------------------------------
  * CrossEntropyLabelSmooth (layers/softmax_loss.py:23-34): *loss += weight * mean_b sum_k -t_bk log softmax(logits_b)_k with

@@ -526,8 +526,8 @@ def test_general_fusion_eval_against_reference_golden(golden, name, C, H, fused)
             P, S, gk = m.ptab, m.stab, "generalFusion.moe.gating_network.gate."
             e0, e1 = "generalFusion.moe.experts.0.expertHead.0.mlp.", "generalFusion.moe.experts.0.expertHead.1.mlp."
             bn1 = (P.f(gk + "linear_re.2.weight"), P.f(gk + "linear_re.2.bias"), S.f(gk + "linear_re.2.running_mean"), S.f(gk + "linear_re.2.running_var"))
-            _, gates = ops.atmoe_eval_fwd(feats, P.f(gk + "linear_re.0.weight"), P.f(gk + "linear_re.0.bias"), bn1, P.f(gk + "q_.weight"),
-                                          P.f(gk + "k_.weight"), P.f(e0 + "0.weight"), P.f(e0 + "0.bias"), P.f(e0 + "2.weight"), P.f(e0 + "2.bias"),
+            gfold = ops.atmoe_fold_keys(P.f(gk + "q_.weight"), P.f(gk + "k_.weight"), H)
+            _, gates = ops.atmoe_eval_fwd(feats, P.f(gk + "linear_re.0.weight"), P.f(gk + "linear_re.0.bias"), bn1, gfold, P.f(e0 + "0.weight"), P.f(e0 + "0.bias"), P.f(e0 + "2.weight"), P.f(e0 + "2.bias"),
                                           S.f(e0 + "2.running_mean"), S.f(e0 + "2.running_var"), P.off(e1 + "0.weight") - P.off(e0 + "0.weight"),
                                           S.off(e1 + "2.running_mean") - S.off(e0 + "2.running_mean"), 1e-5, B, C, H, want_gates=True)
             torch.testing.assert_close(gates.cpu(), e["gate"].reshape(B, H, 7), rtol=2e-4, atol=2e-5)
