@@ -115,19 +115,38 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const TP* __restrict_
 // z[b] = [tokens[b,0,:], mean_{i>=1} tokens[b,i,:]]; block per sample, thread per 4 channels.
 template <typename T>
 __global__ __launch_bounds__(256) void pife_pool_cat_kernel(const T* __restrict__ tok, float* __restrict__ z, int L, int C) {
-  const int b = blockIdx.x;
-  const T* tb = tok + (int64_t)b * L * C;
-  for (int c4 = threadIdx.x; c4 < (C >> 2); c4 += blockDim.x) {
-    const float4 g = io<T>::ld4(tb + c4 * 4);
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int l = 1; l < L; ++l) {
-      const float4 v = io<T>::ld4(tb + (int64_t)l * C + c4 * 4);
+  // grid (images, chunks of 256 columns); thread = (4-column group g of the chunk, token split sp of 4): 8 tokens requested per step.
+  // (One 128-thread workgroup per image walking all L - 1 tokens in sequence took 34 us at 3 images.)
+  __shared__ float4 red[4][64];
+  const int b = blockIdx.x, g = threadIdx.x & 63, sp = threadIdx.x >> 6;
+  const int c4 = blockIdx.y * 64 + g;
+  const bool ok = c4 < (C >> 2);
+  const T* tb = tok + (int64_t)b * L * C + (ok ? c4 * 4 : 0);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int U = 8;
+  for (int l0 = 1 + sp; l0 < L; l0 += 4 * U) {
+    typename io<T>::raw4 r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int l = l0 + 4 * u;
+      r[u] = io<T>::ld4_raw(tb + (int64_t)(l < L ? l : 1) * C);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (l0 + 4 * u >= L) break;
+      const float4 v = io<T>::cvt4(r[u]);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
+  }
+  red[sp][g] = s;
+  __syncthreads();
+  if (sp == 0 && ok) {
+    const float4 a = red[0][g], b1 = red[1][g], c1 = red[2][g], d1 = red[3][g];
     const float inv = 1.f / (float)(L - 1);
     float* zr = z + (int64_t)b * 2 * C;
-    *reinterpret_cast<float4*>(zr + c4 * 4) = g;
-    *reinterpret_cast<float4*>(zr + C + c4 * 4) = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+    *reinterpret_cast<float4*>(zr + c4 * 4) = io<T>::ld4(tb);
+    *reinterpret_cast<float4*>(zr + C + c4 * 4) = make_float4(((a.x + b1.x) + (c1.x + d1.x)) * inv, ((a.y + b1.y) + (c1.y + d1.y)) * inv,
+                                                              ((a.z + b1.z) + (c1.z + d1.z)) * inv, ((a.w + b1.w) + (c1.w + d1.w)) * inv);
   }
 }
 
@@ -274,8 +293,8 @@ extern "C" int demo_embed_tokens(const void* patch, int32_t dt_patch, const floa
 extern "C" int demo_pife_pool_cat(const void* tokens, int32_t dt, float* z, int32_t Bn, int32_t L, int32_t C, void* stream) {
   DEMO_REQUIRE(C % 4 == 0 && L >= 2, "demo_pife_pool_cat: bad shape");
   hipStream_t s = (hipStream_t)stream;
-  if (dt == DEMO_BF16) hipLaunchKernelGGL(pife_pool_cat_kernel<bf16_t>, dim3(Bn), dim3(128), 0, s, (const bf16_t*)tokens, z, L, C);
-  else hipLaunchKernelGGL(pife_pool_cat_kernel<float>, dim3(Bn), dim3(128), 0, s, (const float*)tokens, z, L, C);
+  if (dt == DEMO_BF16) hipLaunchKernelGGL(pife_pool_cat_kernel<bf16_t>, dim3(Bn, (unsigned)cdiv64(C, 256)), dim3(256), 0, s, (const bf16_t*)tokens, z, L, C);
+  else hipLaunchKernelGGL(pife_pool_cat_kernel<float>, dim3(Bn, (unsigned)cdiv64(C, 256)), dim3(256), 0, s, (const float*)tokens, z, L, C);
   DEMO_LAUNCH_CHECK("demo_pife_pool_cat");
   return 0;
 }

@@ -578,6 +578,15 @@ __device__ __forceinline__ void lds_read4(bf16x8 (&f)[4], unsigned base) {
                : "memory");
 }
 
+// two ds_read_b128 of tile rows 0 / 16 from one base; NOT waited for here
+__device__ __forceinline__ void lds_read2(bf16x8 (&f)[2], unsigned base) {
+  asm volatile("ds_read_b128 %0, %2\n\t"
+               "ds_read_b128 %1, %2 offset:2048"
+               : "=&v"(f[0]), "=&v"(f[1])
+               : "v"(base)
+               : "memory");
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -679,7 +688,7 @@ void gemm_bf16_nt_kernel(const FArgs p) {
     slot = slot + 1 == NSTAGE ? 0 : slot + 1;
     const char* la = cur + wr * (TM * 16 * 128);
     const char* lb = cur + A_BYTES + wc * (TN * 16 * 128);
-    if constexpr (TM * TN <= 16) {
+    if constexpr (TM == 4 && TN == 4) {
       // all 2*(TM+TN) fragment reads of the K-step are issued before the first MFMA: one exposed LDS latency per
       // K-step instead of one per 8-MFMA group (the compiler then waits with counted lgkmcnt as data arrives)
       // The reads are inline asm so that the waits can be COUNTED by hand (hipcc waits lgkmcnt(0) for its own loads
@@ -708,6 +717,24 @@ void gemm_bf16_nt_kernel(const FArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[1][j], af[1][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    } else if constexpr (TM == 2 && TN == 2) {
+      // 64^2 tile: the eight fragment reads as inline asm (a compiler-visible LDS load is ordered behind the LDS-DMA writes with
+      // vmcnt(0), which would drain the three K-tiles kept in flight)
+      bf16x8 af[2][2], bfr[2][2];
+      lds_read2(bfr[0], lds_off(lb + foff0));
+      lds_read2(af[0], lds_off(la + foff0));
+      lds_read2(bfr[1], lds_off(lb + foff1));
+      lds_read2(af[1], lds_off(la + foff1));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     } else {
 #pragma unroll
@@ -768,7 +795,7 @@ void gemm_bf16_nt_kernel(const FArgs p) {
       }
     }
     __syncthreads();
-    epi_rows<NIT, RSTEP, BN, 4>(p, ct, threadIdx.x / CPR, m0, n0 + c * 8, c, bz0, bz1, coff, epre, have_epre);
+    epi_rows<NIT, RSTEP, BN, (NIT < 4 ? NIT : 4)>(p, ct, threadIdx.x / CPR, m0, n0 + c * 8, c, bz0, bz1, coff, epre, have_epre);
   } else {
     // direct form: lane holds C[m][n .. n+3] for each of its MFMA tiles
     const int ng = (lane >> 4) * 4;
@@ -784,15 +811,6 @@ void gemm_bf16_nt_kernel(const FArgs p) {
       }
     }
   }
-}
-
-// two ds_read_b128 of tile rows 0 / 16 from one base; NOT waited for here
-__device__ __forceinline__ void lds_read2(bf16x8 (&f)[2], unsigned base) {
-  asm volatile("ds_read_b128 %0, %2\n\t"
-               "ds_read_b128 %1, %2 offset:2048"
-               : "=&v"(f[0]), "=&v"(f[1])
-               : "v"(base)
-               : "memory");
 }
 
 // ---- 256 x 256 ping-pong kernel ----------------------------------------------------------------------------------------
@@ -1246,6 +1264,9 @@ int demo_gemm_bf16_config(const demo_gemm_desc& d) {
     }
   }
   if ((cfg == 2562 || cfg == 2566) && d.N % 256) cfg = 1282;
+  // few rows (inference at small batches: 387 rows at B = 1): 128^2 tiles leave most CUs idle and every workgroup walks K at one exposed
+  // load latency per step (19 us per trunk product at B = 1); 64^2 tiles with three K-tiles in flight
+  if (g_force_tile == 0 && cfg == 1282 && cdiv64(d.M, 128) * cdiv64(d.N, 128) * nb < 128) cfg = 644;
   return cfg;
 }
 
@@ -1329,6 +1350,7 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
   switch (cfg) {
     case 2562: LAUNCH(256, 256, 2, 4, 2); break;
     case 2563: LAUNCH(256, 128, 4, 2, 3); break;
+    case 644: LAUNCH(64, 64, 2, 2, 4); break;        // small-M products (eval at small batches): 4x the workgroups, 3 K-tiles in flight
     case 1283: LAUNCH(128, 128, 2, 2, 3); break;
     case 1284: LAUNCH(128, 128, 2, 2, 4); break;
     case 2566:

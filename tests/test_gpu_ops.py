@@ -91,7 +91,7 @@ def test_gemm_bf16_mfma(M, N, K):
         assert torch.equal(got.cpu(), a2.bfloat16().float() @ b2.bfloat16().float().t())
 
 
-@pytest.mark.parametrize("reg_epi,tile", [(1, 2566), (0, 2566), (1, 2576)])
+@pytest.mark.parametrize("reg_epi,tile", [(1, 2566), (0, 2566), (1, 2576), (1, 644)])
 @pytest.mark.parametrize("M,N,K", [(700, 512, 192), (1300, 256, 64), (256, 768, 128), (3 * 256 + 5, 384, 64)])
 def test_gemm_bf16_256_kernel_epilogues(M, N, K, reg_epi, tile):
     """The 256x256 ping-pong kernel forced (the heuristic only takes it on chip-filling shapes), both epilogue forms: the register
@@ -103,7 +103,7 @@ def test_gemm_bf16_256_kernel_epilogues(M, N, K, reg_epi, tile):
     if K % 64 or (tile == 2566 and N % 256):
         pytest.skip("shape outside this tile configuration's contract")
     lib.demo_gemm_set_pp_epilogue(reg_epi)
-    lib.demo_gemm_force_tile(tile)            # 2566: 256x256 ping-pong kernel; 2576: 256x128 twin kernel (two workgroups per CU, BK = 32)
+    lib.demo_gemm_force_tile(tile)            # 2566: 256x256 ping-pong kernel; 2576: 256x128 twin kernel (two workgroups per CU, BK = 32); 644: 64x64, 4 stages (small M)
     try:
         a2 = torch.zeros(M, K)
         a2[:K, :K] = torch.eye(K)
