@@ -28,6 +28,9 @@ step gemm cost;            python tools/gemm_cost.py > $O/gemm_cost.txt 2>&1 || 
 step attention;            python tools/bench_attn.py > $O/bench_attn.txt 2>&1 || echo FAILED
 step layernorm;            python tools/bench_ln.py > $O/bench_ln.txt 2>&1 || echo FAILED
 step store probe;          tools/probes/store_probe > $O/store_probe.txt 2>&1 || echo FAILED
+step eval latency;         bash tools/eval_latency.sh > $O/eval_latency.txt 2>&1 || echo FAILED
+step eval kernel stats;    bash tools/eval_profile.sh > $O/eval_profile.log 2>&1 || echo FAILED
+for f in b1_f1 b1_f0 b64_f1; do cp gpurun_out/lat/prof_$f/p_kernel_stats.csv $O/fwd_${f}_kernel_stats.csv 2>/dev/null; done
 # keep only the summaries (the raw traces are tens of MB)
 cp $O/stats/t_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
 rm -rf $O/stats $O/pmc_F $O/pmc_W $O/pmc_l2a $O/pmc_l2b $O/pmc_sq $O/pmc_grbm
