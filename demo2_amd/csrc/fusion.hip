@@ -24,7 +24,7 @@ __device__ __forceinline__ uint32_t rng_hash(uint64_t seed, uint64_t idx) {
   return (uint32_t)((z ^ (z >> 31)) >> 32);
 }
 
-template <typename T>
+template <typename T, int U>
 __global__ __launch_bounds__(512) void hdm_softmax_pool_kernel(const float* __restrict__ S, int64_t ldS, const T* __restrict__ tok,
                                                                float* __restrict__ pooled, float* __restrict__ psum,
                                                                float* __restrict__ probs, float* __restrict__ probs_post, int Bs, int L, int C, int Hh,
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(512) void hdm_softmax_pool_kernel(const float* __re
   for (int h = 0; h < HH_MAX; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (split < nsplit) {
     // U tokens per step, all U loads requested before the first is used: a thread walks ~Lk / nsplit tokens (97 at Lk = 387), and one
-    // dependent HBM/L2 round trip per token made this kernel 99 us at B = 1
-    constexpr int U = 8;
+    // dependent HBM/L2 round trip per token made this kernel 99 us at B = 1 (U = 8 on small grids; on chip-filling grids the other
+    // workgroups hide the latency and the extra registers cost occupancy: 147 -> 214 us at B = 128, so U = 1 there)
     for (int lk0 = split; lk0 < Lk; lk0 += U * nsplit) {
       typename io<T>::raw4 xr[U];
 #pragma unroll
@@ -195,10 +195,11 @@ extern "C" int demo_hdm_softmax_pool(const float* S, int64_t ldS, const void* to
   DEMO_REQUIRE(shm <= 64 * 1024, "demo_hdm_softmax_pool: L=%d too long", L);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(Bs, 7);
-  if (dt == DEMO_BF16)
-    hipLaunchKernelGGL(hdm_softmax_pool_kernel<bf16_t>, grid, dim3(512), shm, s, S, ldS, (const bf16_t*)tokens, pooled, psum, probs, probs_post, Bs, L, C, Hh, p_drop, seed, seed_dev);
-  else
-    hipLaunchKernelGGL(hdm_softmax_pool_kernel<float>, grid, dim3(512), shm, s, S, ldS, (const float*)tokens, pooled, psum, probs, probs_post, Bs, L, C, Hh, p_drop, seed, seed_dev);
+  const bool small = (int64_t)Bs * 7 < 512;
+#define HDM_POOL(T_, U_) hipLaunchKernelGGL((hdm_softmax_pool_kernel<T_, U_>), grid, dim3(512), shm, s, S, ldS, (const T_*)tokens, pooled, psum, probs, probs_post, Bs, L, C, Hh, p_drop, seed, seed_dev)
+  if (dt == DEMO_BF16) { if (small) HDM_POOL(bf16_t, 8); else HDM_POOL(bf16_t, 1); }
+  else { if (small) HDM_POOL(float, 8); else HDM_POOL(float, 1); }
+#undef HDM_POOL
   DEMO_LAUNCH_CHECK("demo_hdm_softmax_pool");
   return 0;
 }
