@@ -55,6 +55,7 @@ PROTOTYPES = {
     "demo_gemm_set_dephase": [C.c_int],
     "demo_gemm_set_colslice": [C.c_int],
     "demo_gemm_set_epi_stage": [C.c_int],
+    "demo_gemm_set_split_overlap": [C.c_int],
     "demo_gemm_store_policy": [],
     "demo_cast_f32_bf16": [_P, _P, _L, _P],
     "demo_cast_bf16_f32": [_P, _P, _L, _P],
@@ -152,6 +153,8 @@ def load():
         lib.demo_attention_set_variant(int(os.environ["DEMO_ATTN_VARIANT"]))    # 0: round-1 attention forward (Q, K, V in LDS)
     if "DEMO_GEMM_DEPHASE" in os.environ:
         lib.demo_gemm_set_dephase(int(os.environ["DEMO_GEMM_DEPHASE"]))         # 256x256 kernel: start offsets of the first round
+    if "DEMO_GEMM_SPLIT_OVERLAP" in os.environ:
+        lib.demo_gemm_set_split_overlap(int(os.environ["DEMO_GEMM_SPLIT_OVERLAP"]))   # 1: split remainders on a side stream beside the main part (experiment)
     if "DEMO_GEMM_EPI_STAGE" in os.environ:
         lib.demo_gemm_set_epi_stage(int(os.environ["DEMO_GEMM_EPI_STAGE"]))     # 0: stores straight from the accumulator layout
     if "DEMO_GEMM_COLSLICE" in os.environ:

@@ -1288,6 +1288,34 @@ int demo_gemm_bf16_split_rows(const demo_gemm_desc& d) {
   return (int)(tm1 * 256);
 }
 
+// Side stream of the row split (one per host thread and device: the library is entered from the caller's thread and from autograd's).
+struct SideStream {
+  hipStream_t st = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  int dev = -1;
+};
+static int g_split_overlap = 0;      // opt-in: measured SLOWER (37.5 vs 36.8 ms per step): the two cross-stream event waits per product cost more on
+                                     // the device than the idle CUs they fill; hipExtAnyOrderLaunch (no barrier bit, same stream) is not supported on gfx9
+extern "C" int demo_gemm_set_split_overlap(int on) { g_split_overlap = on ? 1 : 0; return 0; }
+static SideStream* side_stream() {
+  static thread_local SideStream x;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (x.st && x.dev == dev) return &x;
+  if (x.st) {                                        // the thread moved to another device: start over there
+    hipStreamDestroy(x.st); hipEventDestroy(x.fork); hipEventDestroy(x.join);
+    x = SideStream();
+  }
+  if (hipStreamCreateWithFlags(&x.st, hipStreamNonBlocking) != hipSuccess) { x = SideStream(); return nullptr; }
+  if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) {
+    hipStreamDestroy(x.st);
+    x = SideStream();
+    return nullptr;
+  }
+  x.dev = dev;
+  return &x;
+}
+
 // cfg_override: 0 = choose by the heuristic (and split by rows where that pays), otherwise the configuration code to launch.  The two
 // parts of a split product are issued through the override, not through the g_force_tile test hook: the library is entered from two
 // threads (forward on the caller's, backward on autograd's) and must not pass state between calls through a global.
@@ -1306,6 +1334,18 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
     if (d.residual) b.residual = (const char*)d.residual + (int64_t)m1 * d.c_rs * (d.dtRes == DEMO_BF16 ? 2 : 4);
     if (d.act_grad_pre) b.act_grad_pre = (const char*)d.act_grad_pre + (int64_t)m1 * d.c_rs * szP;
     if (d.pre_out) b.pre_out = (char*)d.pre_out + (int64_t)m1 * d.c_rs * szC;
+    // The two parts touch disjoint rows.  Issued back to back on one stream, the remainder runs alone on about half the CUs (282 small
+    // tiles at 2 per CU).  Opt-in experiment (demo_gemm_set_split_overlap): forked onto a side stream it is ready at the same moment as the
+    // main part and the caller's stream joins both before anything else runs.
+    SideStream* side = g_split_overlap ? side_stream() : nullptr;
+    if (side && hipEventRecord(side->fork, s) == hipSuccess && hipStreamWaitEvent(side->st, side->fork, 0) == hipSuccess) {
+      int rc = demo_gemm_bf16_launch(b, side->st, 1282);
+      const hipError_t e1 = hipEventRecord(side->join, side->st);
+      if (rc == 0) rc = demo_gemm_bf16_launch(a, s, 2566);
+      const hipError_t e2 = hipStreamWaitEvent(s, side->join, 0);
+      if (rc == 0 && (e1 != hipSuccess || e2 != hipSuccess)) DEMO_FAIL(-2, "demo_gemm: joining the side stream failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+      return rc;
+    }
     int rc = demo_gemm_bf16_launch(a, s, 2566);
     if (rc == 0) rc = demo_gemm_bf16_launch(b, s, 1282);
     return rc;
