@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, NT <= 9 ? 2 : 1) void attn_bwd_bf16_kernel(con
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               pv[r] = __builtin_amdgcn_exp2f(s[r] * c2 - l2[hh][r]);
-              dv[r] = pv[r] * (dp[r] - dl[hh][r]) * scale;
+              dv[r] = pv[r] * (dp[r] - dl[hh][r]);               // (* scale: folded into dK at the store -- 16 multiplies per lane and key tile instead of one per element)
             }
             pw[hh * 2] = pack_bf16x2(pv[0], pv[1]); pw[hh * 2 + 1] = pack_bf16x2(pv[2], pv[3]);
             dw[hh * 2] = pack_bf16x2(dv[0], dv[1]); dw[hh * 2 + 1] = pack_bf16x2(dv[2], dv[3]);
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, NT <= 9 ? 2 : 1) void attn_bwd_bf16_kernel(con
           bf16_t* row = dqkv + ((int64_t)b * L + key) * ld3 + h * 64 + 4 * g;
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) {
-            io<bf16_t>::st4(row + D + dt * 16, make_float4(dKa[a][dt][0], dKa[a][dt][1], dKa[a][dt][2], dKa[a][dt][3]));
+            io<bf16_t>::st4(row + D + dt * 16, make_float4(dKa[a][dt][0] * scale, dKa[a][dt][1] * scale, dKa[a][dt][2] * scale, dKa[a][dt][3] * scale));
             io<bf16_t>::st4(row + 2 * D + dt * 16, make_float4(dVa[a][dt][0], dVa[a][dt][1], dVa[a][dt][2], dVa[a][dt][3]));
           }
         }
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, NT <= 9 ? 2 : 1) void attn_bwd_bf16_kernel(con
           dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, gf1, dp, 0, 0, 0);
           float dv[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dv[r] = __builtin_amdgcn_exp2f(s[r] * c2 - l2q) * (dp[r] - dlq) * scale;
+          for (int r = 0; r < 4; ++r) dv[r] = __builtin_amdgcn_exp2f(s[r] * c2 - l2q) * (dp[r] - dlq);      // (* scale: at the dQ store)
           dsw[hh * 2] = pack_bf16x2(dv[0], dv[1]);
           dsw[hh * 2 + 1] = pack_bf16x2(dv[2], dv[3]);
         }
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, NT <= 9 ? 2 : 1) void attn_bwd_bf16_kernel(con
         bf16_t* row = dqkv + ((int64_t)b * L + q) * ld3 + h * 64 + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
-          io<bf16_t>::st4(row + dt * 16, make_float4(dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]));
+          io<bf16_t>::st4(row + dt * 16, make_float4(dq[dt][0] * scale, dq[dt][1] * scale, dq[dt][2] * scale, dq[dt][3] * scale));
       }
     }
   }
