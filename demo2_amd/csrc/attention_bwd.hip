@@ -47,6 +47,28 @@ __device__ __forceinline__ bf16x8 tr_frag_opt(const char* base, int off_lo, int 
   return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// Output rows: an accumulator tile gives a lane 4 consecutive d (8 B of bf16) of its key / query row, 16 rows x 32 B per store
+// instruction.  v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of another: applied to the packed
+// halves of the column tiles 2p and 2p+1 it leaves every lane with 8 consecutive d (16 B) -- even lane groups g own tile 2p at
+// d = 4g .. 4g+7, odd groups tile 2p+1 at d = 4(g-1) .. 4(g-1)+7 -- so a row leaves in half as many store instructions, 16 B each.
+// (the swaps run with every lane of the wave active; `ok` guards only the store)
+__device__ __forceinline__ void store_rows16(bf16_t* row, int g, const f32x4 (&t)[4], float scale, bool ok) {
+  uint32_t lo[4], hi[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    lo[dt] = pack_bf16x2(t[dt][0] * scale, t[dt][1] * scale);
+    hi[dt] = pack_bf16x2(t[dt][2] * scale, t[dt][3] * scale);
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const auto a = __builtin_amdgcn_permlane16_swap(lo[2 * p], lo[2 * p + 1], false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi[2 * p], hi[2 * p + 1], false, false);
+    // even g: {own tile 2p (d 4g..4g+3), tile 2p of group g+1 (d 4g+4..4g+7)}; odd g: {tile 2p+1 of group g-1, own tile 2p+1}
+    const int d0 = (g & 1) ? (2 * p + 1) * 16 + 4 * (g - 1) : 2 * p * 16 + 4 * g;
+    if (ok) *reinterpret_cast<uint4*>(row + d0) = make_uint4(a[0], b[0], a[1], b[1]);
+  }
+}
+
 template <int NT>
 __global__ __launch_bounds__(256, NT <= 9 ? 2 : 1) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv,
                                                                              const bf16_t* __restrict__ out,
@@ -210,20 +232,15 @@ __global__ __launch_bounds__(256, NT <= 9 ? 2 : 1) void attn_bwd_bf16_kernel(con
     };
     for (int qp = 0; qp < NT / 2; ++qp) pass_a(qp, std::true_type{});
     if constexpr (NT & 1) pass_a(NT / 2, std::false_type{});
-    // dK^T / dV^T tiles: D[row = d = 4g + reg][col = key = li] -> 4 consecutive d per lane
+    // dK^T / dV^T tiles: D[row = d = 4g + reg][col = key = li] -> 4 consecutive d per lane, 8 after the row-pair exchange (store_rows16)
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const int kt = wave + 4 * a;
       if (kt < NT) {
         const int key = kt * 16 + li;
-        if (key < L) {
-          bf16_t* row = dqkv + ((int64_t)b * L + key) * ld3 + h * 64 + 4 * g;
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
-            io<bf16_t>::st4(row + D + dt * 16, make_float4(dKa[a][dt][0] * scale, dKa[a][dt][1] * scale, dKa[a][dt][2] * scale, dKa[a][dt][3] * scale));
-            io<bf16_t>::st4(row + 2 * D + dt * 16, make_float4(dVa[a][dt][0], dVa[a][dt][1], dVa[a][dt][2], dVa[a][dt][3]));
-          }
-        }
+        bf16_t* row = dqkv + ((int64_t)b * L + (key < L ? key : 0)) * ld3 + h * 64;
+        store_rows16(row + D, g, dKa[a], scale, key < L);
+        store_rows16(row + 2 * D, g, dVa[a], 1.0f, key < L);
       }
     }
   }
@@ -279,12 +296,7 @@ __global__ __launch_bounds__(256, NT <= 9 ? 2 : 1) void attn_bwd_bf16_kernel(con
       for (int kp = 0; kp < NT / 2; ++kp) pass_b(kp, std::true_type{});
       if constexpr (NT & 1) pass_b(NT / 2, std::false_type{});
       const int q = qtile * 16 + li;
-      if (q < L) {
-        bf16_t* row = dqkv + ((int64_t)b * L + q) * ld3 + h * 64 + 4 * g;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-          io<bf16_t>::st4(row + dt * 16, make_float4(dq[dt][0] * scale, dq[dt][1] * scale, dq[dt][2] * scale, dq[dt][3] * scale));
-      }
+      store_rows16(dqkv + ((int64_t)b * L + (q < L ? q : 0)) * ld3 + h * 64, g, dq, scale, q < L);
     }
   }
 }
