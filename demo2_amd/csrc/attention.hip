@@ -152,14 +152,9 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_bf16_kv_kernel(const bf16_t* 
       }
     }
     const int q = qt * 16 + li;
-    if (q < L) {
-      const float inv = 1.f / sum;
-      bf16_t* orow = out + ((int64_t)b * L + q) * D + h * 64 + 4 * g;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        io<bf16_t>::st4(orow + dt * 16, make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv));
-      if (lse && g == 0) lse[((int64_t)b * H + h) * L + q] = m * scale + __logf(sum);
-    }
+    // 16-B row stores (store_rows16, common.h): the lanes exchanged hold the same query, so each scales by its own 1 / sum first
+    store_rows16(out + ((int64_t)b * L + (q < L ? q : 0)) * D + h * 64, g, o, 1.f / sum, q < L);
+    if (q < L && lse && g == 0) lse[((int64_t)b * H + h) * L + q] = m * scale + __logf(sum);
   }
 }
 
@@ -283,14 +278,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
       }
     }
     const int q = qt * 16 + li;
-    if (q < L) {
-      const float inv = 1.f / sum;
-      bf16_t* orow = out + ((int64_t)b * L + q) * D + h * 64 + 4 * g;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        io<bf16_t>::st4(orow + dt * 16, make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv));
-      if (lse && g == 0) lse[((int64_t)b * H + h) * L + q] = m * scale + __logf(sum);
-    }
+    // 16-B row stores (store_rows16, common.h): the lanes exchanged hold the same query, so each scales by its own 1 / sum first
+    store_rows16(out + ((int64_t)b * L + (q < L ? q : 0)) * D + h * 64, g, o, 1.f / sum, q < L);
+    if (q < L && lse && g == 0) lse[((int64_t)b * H + h) * L + q] = m * scale + __logf(sum);
   }
 }
 

@@ -142,4 +142,27 @@ __device__ __forceinline__ float act_both(float x, int act, float& d) {
   return x;
 }
 
+// ---- attention kernels: 16-B output rows ----------------------------------------------------------------------------------------
+// Output rows: an accumulator tile gives a lane 4 consecutive d (8 B of bf16) of its key / query row, 16 rows x 32 B per store
+// instruction.  v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of another: applied to the packed
+// halves of the column tiles 2p and 2p+1 it leaves every lane with 8 consecutive d (16 B) -- even lane groups g own tile 2p at
+// d = 4g .. 4g+7, odd groups tile 2p+1 at d = 4(g-1) .. 4(g-1)+7 -- so a row leaves in half as many store instructions, 16 B each.
+// (the swaps run with every lane of the wave active; `ok` guards only the store)
+__device__ __forceinline__ void store_rows16(bf16_t* row, int g, const f32x4 (&t)[4], float scale, bool ok) {
+  uint32_t lo[4], hi[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    lo[dt] = pack_bf16x2(t[dt][0] * scale, t[dt][1] * scale);
+    hi[dt] = pack_bf16x2(t[dt][2] * scale, t[dt][3] * scale);
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const auto a = __builtin_amdgcn_permlane16_swap(lo[2 * p], lo[2 * p + 1], false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi[2 * p], hi[2 * p + 1], false, false);
+    // even g: {own tile 2p (d 4g..4g+3), tile 2p of group g+1 (d 4g+4..4g+7)}; odd g: {tile 2p+1 of group g-1, own tile 2p+1}
+    const int d0 = (g & 1) ? (2 * p + 1) * 16 + 4 * (g - 1) : 2 * p * 16 + 4 * g;
+    if (ok) *reinterpret_cast<uint4*>(row + d0) = make_uint4(a[0], b[0], a[1], b[1]);
+  }
+}
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
