@@ -52,8 +52,9 @@ PROTOTYPES = {
     "demo_gemm_set_split": [C.c_int],
     "demo_gemm_set_pp_epilogue": [C.c_int],
     "demo_gemm_set_pp_min_fill": [C.c_int],
+    "demo_gemm_set_dephase": [C.c_int],
+    "demo_gemm_set_colslice": [C.c_int],
     "demo_gemm_set_epi_stage": [C.c_int],
-    "demo_gemm_set_persist": [C.c_int],
     "demo_gemm_set_split_overlap": [C.c_int],
     "demo_gemm_store_policy": [],
     "demo_cast_f32_bf16": [_P, _P, _L, _P],
@@ -150,12 +151,14 @@ def load():
         lib.demo_gemm_set_pp_min_fill(int(os.environ["DEMO_PP_MIN_FILL"]))      # 85: the pre-register-epilogue kernel choice
     if "DEMO_ATTN_VARIANT" in os.environ:
         lib.demo_attention_set_variant(int(os.environ["DEMO_ATTN_VARIANT"]))    # 0: round-1 attention forward (Q, K, V in LDS)
+    if "DEMO_GEMM_DEPHASE" in os.environ:
+        lib.demo_gemm_set_dephase(int(os.environ["DEMO_GEMM_DEPHASE"]))         # 256x256 kernel: start offsets of the first round
     if "DEMO_GEMM_SPLIT_OVERLAP" in os.environ:
         lib.demo_gemm_set_split_overlap(int(os.environ["DEMO_GEMM_SPLIT_OVERLAP"]))   # 1: split remainders on a side stream beside the main part (experiment)
-    if "DEMO_GEMM_PERSIST" in os.environ:
-        lib.demo_gemm_set_persist(int(os.environ["DEMO_GEMM_PERSIST"]))         # 0: one tile per workgroup (256x256 kernel)
     if "DEMO_GEMM_EPI_STAGE" in os.environ:
         lib.demo_gemm_set_epi_stage(int(os.environ["DEMO_GEMM_EPI_STAGE"]))     # 0: stores straight from the accumulator layout
+    if "DEMO_GEMM_COLSLICE" in os.environ:
+        lib.demo_gemm_set_colslice(int(os.environ["DEMO_GEMM_COLSLICE"]))       # 256x256 kernel: weight-panel slices per launch (1 = off)
     if "DEMO_GEMM_SPLIT" in os.environ:
         lib.demo_gemm_set_split(int(os.environ["DEMO_GEMM_SPLIT"]))             # 0: no row split of partial-round products
     _lib = lib

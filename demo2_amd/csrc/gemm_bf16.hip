@@ -39,8 +39,9 @@ struct FArgs {
   float alpha;
   int ntm, ntn;
   int group_m;                 // 256^2 kernel: row panels per tile-order group
-  int persist;                 // 256^2 kernel: > 0 = persistent walk with this stride (= the grid size), 0 = one tile per workgroup
+  int dephase;                 // 256^2 kernel, tuning hook: first-round workgroups start ((id >> 3) & 3) * dephase * 64 clocks late
   int epi_stage;               // 256^2 kernel, register epilogue: bf16 outputs leave through an LDS image of the tile (whole-row stores)
+  int colslice;                // 256^2 kernel: > 1 = every XCD keeps to ntn / colslice weight panels for the whole launch (see the kernel)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -375,50 +376,11 @@ __device__ __forceinline__ void epi_rows(const FArgs& p, const float* __restrict
 // 512 B over the main loop's ring, 16-B chunk index XOR (row & 31) -- from which every wave drains 32 whole rows, two per store
 // instruction (~20 B/clk per CU).  SINK 2 (two outputs: fc1 forward) works the tile in two 128-row halves, each with a 64-KB image per output.
 __device__ __forceinline__ unsigned pp_tile_slot(int row, int chunk) { return (unsigned)(row * 512 + ((chunk ^ (row & 31)) << 4)); }
-// The image is written and read with INLINE-ASM LDS instructions and raw barriers: in the persistent form of the kernel the next tile's
-// first activation K-tile is already on its way into LDS (LDS-DMA) while the image is in use, and a compiler-visible LDS access is
-// ordered behind every pending LDS-DMA with s_waitcnt vmcnt(0) -- which would wait for that prefetch (and for the epilogue's own
-// global stores) in the middle of the epilogue.
-__device__ __forceinline__ void lds_write16(unsigned addr, const u32x4 v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
-__device__ __forceinline__ void lds_read16(u32x4& v, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory"); }
-__device__ __forceinline__ void lds_done_barrier() {        // every wave's LDS accesses so far are complete
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-}
-// s_waitcnt lgkmcnt(N) tied to the register it releases (in / out operand): whatever uses `v` is ordered behind the wait, so a drain
-// can store row `it` as soon as its own read has returned instead of waiting for all sixteen
-template <int N> __device__ __forceinline__ void lds_wait_for(u32x4& v) {
-  static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
-  if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));
-  else if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(v));
-  else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(v));
-  else if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(v));
-  else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(v));
-  else if constexpr (N == 5) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(v));
-  else if constexpr (N == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(v));
-  else if constexpr (N == 7) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(v));
-  else if constexpr (N == 8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(v));
-  else if constexpr (N == 9) asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(v));
-  else if constexpr (N == 10) asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(v));
-  else if constexpr (N == 11) asm volatile("s_waitcnt lgkmcnt(11)" : "+v"(v));
-  else if constexpr (N == 12) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(v));
-  else if constexpr (N == 13) asm volatile("s_waitcnt lgkmcnt(13)" : "+v"(v));
-  else if constexpr (N == 14) asm volatile("s_waitcnt lgkmcnt(14)" : "+v"(v));
-  else asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(v));
-}
-template <int NR, int IT = 0> __device__ __forceinline__ void lds_wait_each(u32x4 (&r)[NR]) {
-  if constexpr (IT < NR) {
-    lds_wait_for<NR - 1 - IT>(r[IT]);
-    lds_wait_each<NR, IT + 1>(r);
-  }
-}
-__device__ __forceinline__ void pp_drain(const FArgs& p, void* out, unsigned lds, int m0, int n0, int64_t coff, int wave, int lane) {
+__device__ __forceinline__ void pp_drain(const FArgs& p, void* out, const char* lds, int m0, int n0, int64_t coff, int wave, int lane) {
   u32x4 r[16];
   const int rsub = lane >> 5, chunk = lane & 31;
 #pragma unroll
-  for (int it = 0; it < 16; ++it) lds_read16(r[it], lds + pp_tile_slot(wave * 32 + it * 2 + rsub, chunk));
-  lds_wait_each<16>(r);
+  for (int it = 0; it < 16; ++it) r[it] = *reinterpret_cast<const u32x4*>(lds + pp_tile_slot(wave * 32 + it * 2 + rsub, chunk));
 #pragma unroll
   for (int it = 0; it < 16; ++it) {
     const int m = m0 + wave * 32 + it * 2 + rsub;
@@ -426,13 +388,12 @@ __device__ __forceinline__ void pp_drain(const FArgs& p, void* out, unsigned lds
   }
 }
 // half images of SINK 2: 128 image rows = the 64-row half `half` of both wave rows; 16 image rows per wave
-__device__ __forceinline__ void pp_drain_half(const FArgs& p, void* out, unsigned img, int m0, int n0, int64_t coff, int half, int wave,
+__device__ __forceinline__ void pp_drain_half(const FArgs& p, void* out, const char* img, int m0, int n0, int64_t coff, int half, int wave,
                                               int lane) {
   u32x4 r[8];
   const int rsub = lane >> 5, chunk = lane & 31;
 #pragma unroll
-  for (int it = 0; it < 8; ++it) lds_read16(r[it], img + pp_tile_slot(wave * 16 + it * 2 + rsub, chunk));
-  lds_wait_each<8>(r);
+  for (int it = 0; it < 8; ++it) r[it] = *reinterpret_cast<const u32x4*>(img + pp_tile_slot(wave * 16 + it * 2 + rsub, chunk));
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int hr = wave * 16 + it * 2 + rsub;
@@ -442,7 +403,7 @@ __device__ __forceinline__ void pp_drain_half(const FArgs& p, void* out, unsigne
 }
 template <int G, int ACT, int GK, int LOADS, int SINK = 0>
 __device__ __forceinline__ void pp_epi_k(const FArgs& p, const f32x4 (&acc)[8][4], int mrow, int ncol, int64_t coff, const float* bias,
-                                         unsigned lds = 0, int m0 = 0, int n0 = 0, int lane = 0, int wave = 0) {
+                                         char* lds = nullptr, int m0 = 0, int n0 = 0) {
   const bool has_pre = LOADS >= 0 ? (LOADS & 2) != 0 : (GK >= 0 ? GK != DEMO_ACT_NONE : p.pre != nullptr);
   const bool has_res = LOADS >= 0 ? (LOADS & 1) != 0 : p.residual != nullptr;
   const bool has_old = LOADS >= 0 ? false : (p.accumulate && p.dtC == DEMO_F32);
@@ -538,48 +499,50 @@ __device__ __forceinline__ void pp_epi_k(const FArgs& p, const f32x4 (&acc)[8][4
           epi8_compute<ACT, GK>(p, bz[h][0], bz[h][1], x[u][h], v, sv);
           const int ch = ((ncol - n0) >> 3) + h * 4;
           if constexpr (SINK == 1) {
-            lds_write16(lds + pp_tile_slot(mrow - m0 + (i0 + u) * 16, ch), as_u32x4(f32x8_to_bf16(v)));
+            *reinterpret_cast<u32x4*>(lds + pp_tile_slot(mrow - m0 + (i0 + u) * 16, ch)) = as_u32x4(f32x8_to_bf16(v));
           } else {                                   // two 128-row half images (C, second output): image row = wr * 64 + (i & 3) * 16 + frow
             const int hr = (mrow - m0) - ((mrow - m0) >> 7) * 64 + ((i0 + u) & 3) * 16;
-            lds_write16(lds + pp_tile_slot(hr, ch), as_u32x4(f32x8_to_bf16(v)));
-            lds_write16(lds + 65536 + pp_tile_slot(hr, ch), as_u32x4(f32x8_to_bf16(sv)));
+            *reinterpret_cast<u32x4*>(lds + pp_tile_slot(hr, ch)) = as_u32x4(f32x8_to_bf16(v));
+            *reinterpret_cast<u32x4*>(lds + 65536 + pp_tile_slot(hr, ch)) = as_u32x4(f32x8_to_bf16(sv));
           }
         }
       }
     }
     if constexpr (SINK == 2) {                       // (G = 1) the wave's row tiles 0..3, then 4..7: drain both half images
       if (i0 + G == 4 || i0 + G == 8) {
-        lds_done_barrier();
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        __syncthreads();
         pp_drain_half(p, p.C, lds, m0, n0, coff, (i0 + G) / 4 - 1, wave, lane);
         pp_drain_half(p, p.pre_out, lds + 65536, m0, n0, coff, (i0 + G) / 4 - 1, wave, lane);
-        if (i0 + G == 4) lds_done_barrier();
+        if (i0 + G == 4) __syncthreads();
       }
     }
   }
   if constexpr (SINK == 1) {
-    lds_done_barrier();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
     pp_drain(p, p.C, lds, m0, n0, coff, wave, lane);
   }
 }
 __device__ __forceinline__ void pp_epi(const FArgs& p, const f32x4 (&acc)[8][4], int mrow, int ncol, int64_t coff, const float* bias,
-                                       unsigned lds = 0, int m0 = 0, int n0 = 0, int lane = 0, int wave = 0) {
+                                       char* lds = nullptr, int m0 = 0, int n0 = 0) {
   const int gk = p.pre ? p.act_grad_kind : DEMO_ACT_NONE;
   const bool old = p.accumulate && p.dtC == DEMO_F32;
   if (lds && p.epi_stage && p.dtC == DEMO_BF16) {                   // whole-row stores through an LDS image of the tile (bf16 outputs)
     if (!p.pre && !p.residual) {
       if (p.pre_out) {                                       // fc1 forward: two outputs (pre-activation or act')
-        if (p.act == DEMO_ACT_QUICKGELU) { pp_epi_k<1, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE, 0, 2>(p, acc, mrow, ncol, coff, bias, lds, m0, n0, lane, wave); return; }
-        if (p.act == DEMO_ACT_GELU) { pp_epi_k<1, DEMO_ACT_GELU, DEMO_ACT_NONE, 0, 2>(p, acc, mrow, ncol, coff, bias, lds, m0, n0, lane, wave); return; }
+        if (p.act == DEMO_ACT_QUICKGELU) { pp_epi_k<1, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE, 0, 2>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
+        if (p.act == DEMO_ACT_GELU) { pp_epi_k<1, DEMO_ACT_GELU, DEMO_ACT_NONE, 0, 2>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
       } else {
-        if (p.act == DEMO_ACT_NONE) { pp_epi_k<1, DEMO_ACT_NONE, DEMO_ACT_NONE, 0, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0, lane, wave); return; }
-        if (p.act == DEMO_ACT_QUICKGELU) { pp_epi_k<1, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE, 0, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0, lane, wave); return; }
+        if (p.act == DEMO_ACT_NONE) { pp_epi_k<1, DEMO_ACT_NONE, DEMO_ACT_NONE, 0, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
+        if (p.act == DEMO_ACT_QUICKGELU) { pp_epi_k<1, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE, 0, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
       }
     } else if (p.residual && p.dtRes == DEMO_BF16 && !p.pre && !p.pre_out && p.act == DEMO_ACT_NONE) {
-      pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_NONE, 5, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0, lane, wave);
+      pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_NONE, 5, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0);
       return;
     } else if (p.pre && p.dtPre == DEMO_BF16 && !p.residual && !p.pre_out && p.act == DEMO_ACT_NONE) {
-      if (gk == DEMO_ACT_SAVED) { pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_SAVED, 2, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0, lane, wave); return; }
-      if (gk == DEMO_ACT_QUICKGELU) { pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_QUICKGELU, 2, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0, lane, wave); return; }
+      if (gk == DEMO_ACT_SAVED) { pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_SAVED, 2, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
+      if (gk == DEMO_ACT_QUICKGELU) { pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_QUICKGELU, 2, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
     }
   }
   if (!p.pre && !p.residual && !old) {                       // nothing to read but the bias: trunk qkv / fc1 forward, plain dX products
@@ -878,65 +841,80 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
   __shared__ __attribute__((aligned(1024))) char smem[3 * A_BYTES + 2 * B_BYTES];
   char* const smem_b = smem + 3 * A_BYTES;
 
-  const int lane_id = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
 
-  // XCD-aware tile order (as in the 128^2 kernel): workgroup id -> output tile.  Group of row panels walked against all weight panels:
-  // sized so that the ~32 workgroups an XCD runs at a time cover ALL ntn tiles of each of their row panels -- the cold operand
-  // (activations, 76..304 MB) is then fetched once, and it is the hot one (the weight matrix, <= 5 MB) that gets re-read.
+  // XCD-aware tile id (as in the 128^2 kernel).  One output tile per workgroup: a persistent variant (256 workgroups walking
+  // their XCD's tile list, the next tile's first K-tiles requested before the epilogue) was measured twice -- with the LDS-staged
+  // epilogue (no faster, +30 VGPRs) and with the register epilogue, where the LDS is free during the epilogue (qkv forward 179 ->
+  // 211 us, fc1 forward 295 -> 334: the loop-carried addresses spill, the static tile assignment loses the dispatcher's dynamic
+  // balancing, and the wait for the next tile's loads also waits for the epilogue's stores).
+  // Round 2 built it a third time (commit 3a7f73c and its follow-up experiment): 256 workgroups walking tiles id, id + 256, ..., every
+  // per-lane constant derived from a lane id recomputed per tile (mbcnt) so that nothing is hoisted and spilled, the epilogue's LDS
+  // traffic as inline asm (a compiler-visible LDS access waits vmcnt(0) for the pending LDS-DMA prefetch), and (a) the next tile's A(0)
+  // or (b) its whole first K-tile (A slots 0 / 1, B slot 1; image in the 64 KB of A slot 2 + B slot 0, two steps; entry wait
+  // vmcnt(#stores)) requested before the epilogue.  Same-box three-way A/B against this kernel: (a) qkv forward 204.3 -> 198.5 us, fc1
+  // forward 331 -> 323, step 36.26 -> 36.23 ms; (b) qkv 202.5 -> 198.1, fc1 334.6 -> 324.0, but the load-carrying epilogues lose their
+  // early operand requests to the stepwise image (act' product 285 -> 307 us) and the step reads 37.1 -> 37.5 ms.  The walk itself is worth
+  // ~5 % on K = 768 (the same code with one tile per workgroup is that much slower), the scaffolding costs 3 %: not kept.
   const int nwg = p.ntm * p.ntn;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+  const int tid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  // group of row panels walked against all weight panels: sized so that the ~32 workgroups an XCD runs at a time cover ALL
+  // ntn tiles of each of their row panels -- the cold operand (activations, 76..304 MB) is then fetched once, and it is the
+  // hot one (the weight matrix, <= 5 MB, L2 / Infinity-Cache resident) that gets re-read
   const int group_m = p.group_m;
-  auto tile_of = [&](int bid, int& m0, int& n0) -> bool {
-    const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
-    if (bid >= nwg) return false;
-    const int tid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  int m0, n0;
+  if (p.colslice > 1) {
+    // Column-sliced order: XCD x keeps to weight panels [slice * c, (slice + 1) * c) (slice = x % S, c = ntn / S) for the whole launch
+    // and walks its share (one of 8 / S) of the row panels against them.  The slice (c * 393 KB at K = 768) then stays in the XCD's
+    // 4-MB L2 from one round of tiles to the next, where the whole matrix (3.5 .. 4.7 MB) plus the streaming activations does not.
+    const int S = p.colslice, R = 8 / S, c = p.ntn / S;
+    const int j = bid >> 3, slice = xcd % S, rs = xcd / S;
+    const int rbase = p.ntm / R, rrem = p.ntm - rbase * R;
+    const int rows = rbase + (rs < rrem ? 1 : 0), row0 = rs * rbase + (rs < rrem ? rs : rrem);
+    if (j >= rows * c) return;                       // (the grid is 8 x the largest share)
+    const int per_group = group_m * c;
+    const int grp = j / per_group, in_grp = j - grp * per_group;
+    const int gm0 = grp * group_m;
+    const int gsz = (rows - gm0) < group_m ? (rows - gm0) : group_m;
+    m0 = (row0 + gm0 + in_grp % gsz) * BM;
+    n0 = (slice * c + in_grp / gsz) * BN;
+  } else {
     const int per_group = group_m * p.ntn;
     const int grp = tid / per_group, in_grp = tid - grp * per_group;
     const int gm0 = grp * group_m;
     const int gsz = (p.ntm - gm0) < group_m ? (p.ntm - gm0) : group_m;
     m0 = (gm0 + in_grp % gsz) * BM;
     n0 = (in_grp / gsz) * BN;
-    return true;
-  };
-  int bid = blockIdx.x;
-  int m0, n0;
-  if (!tile_of(bid, m0, n0)) return;
+  }
   const int z = blockIdx.y;
   const bf16_t* A = p.A + z * p.sA;
   const bf16_t* B = p.B + z * p.sB;
 
-  const int nk = p.K / BK;
-
-  // PERSISTENT form (p.persist = stride of the walk, 0 = one tile per workgroup): a workgroup walks tiles bid, bid + stride, ... and
-  // requests the NEXT tile's first activation K-tile (A slot 0, free once the ring has wrapped: nk % 3 == 0, checked by the host) before
-  // its epilogue, whose LDS image lies behind that slot: the tile-to-tile gap loses the workgroup launch and the HBM latency of that
-  // first load.  (Round 1 measured two persistent forms slower -- spilled loop-carried addresses, and a compiler-inserted vmcnt(0)
-  // before the first LDS access of the epilogue that waited for the prefetch; here the tile coordinates are recomputed from a
-  // scalar id and the epilogue's LDS traffic is inline asm.)
-  bool a0_staged = false;
-  for (;;) {
-  // Every per-lane constant of a tile (fragment offsets, the LDS-DMA's source rows, the epilogue's rows and columns) is derived from a
-  // LAUNDERED copy of the lane id: derived from the lane id itself they are invariants of the tile loop, get hoisted above it and are
-  // kept -- in scratch -- across iterations (what made round 1's persistent forms spill); recomputing them once per tile is free.  The copy is the
-  // lane's rank in the (full) EXEC mask, so not even the lane id is carried across iterations.
-  int lane_seed = 0;
-  asm volatile("" : "+s"(lane_seed));              // (opaque per iteration: the lane id below is recomputed, not carried in a register)
-  int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, lane_seed));      // every lane is active here
   const int frow = lane & 15;
   const int sw = (lane >> 1) & 7;
   const int foff0 = frow * 128 + (((lane >> 4)) ^ sw) * 16;
   const int foff1 = frow * 128 + ((4 + (lane >> 4)) ^ sw) * 16;
+  const int nk = p.K / BK;
+
   f32x4 acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // (De-phasing the first round of workgroups with s_sleep -- 2/4/8 phase groups 7..17 us apart in round 1, 0.5..4 us offsets in round 2,
-  // before and after the whole-row stores -- never measured faster; the hook is gone, the record is in DESIGN.md.)
+  // (De-phasing the first round of workgroups with s_sleep, so that CUs do not reach their store-heavy epilogues together,
+  // was tried in round 1 -- 2/4/8 phase groups, 7..17 us apart -- and measured 2..6 % slower on the training step.  Round 2
+  // re-measured it with small offsets behind a tuning hook (demo_gemm_set_dephase), see DESIGN.md.)
+  if (p.dephase > 0 && bid < 256) {
+    const int n = ((bid >> 3) & 3) * p.dephase;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+  }
   // first K-tiles: A(0) -> A slot 0, B(0) -> B slot 1, A(1) -> A slot 1
-  if (!a0_staged) stage_tile<BM, NW, false, DEMO_A_AUX>(A, p.lda, m0, p.M, 0, smem, wave, lane);
+  stage_tile<BM, NW, false, DEMO_A_AUX>(A, p.lda, m0, p.M, 0, smem, wave, lane);
   stage_tile<BN, NW, REG_EPI>(B, p.ldb, n0, p.N, 0, smem_b + B_BYTES, wave, lane);
   if (nk > 1) {
     stage_tile<BM, NW, false, DEMO_A_AUX>(A, p.lda, m0, p.M, BK, smem + A_BYTES, wave, lane);
@@ -1060,33 +1038,21 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
   // ---- epilogue: the fp32 tile goes through LDS one 128-row half at a time (whole-row 16-B accesses for bias / act'(pre) /
   // residual / C, see the 128^2 kernel).  Code size matters here: epi4 carries every epilogue variant, and a fully unrolled
   // four-quarter form of this loop (3x the instructions) measured 25 % slower end to end on K = 768 -- instruction fetch.
+  const int64_t coff = z * p.sC;
+  const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
+  const int g4 = lane >> 4;
   if constexpr (REG_EPI) {
-    const int64_t coff = z * p.sC;
-    const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
-    // next tile of this workgroup (persistent form): its first activation K-tile goes out now, into A slot 0 (the epilogue's image
-    // starts behind it)
-    int m0n = 0, n0n = 0;
-    const int nbid = bid + p.persist;
-    const bool more = p.persist > 0 && tile_of(nbid, m0n, n0n);
-    if (more) stage_tile<BM, NW, false, DEMO_A_AUX>(A, p.lda, m0n, p.M, 0, smem, wave, lane);
-    // register epilogue (see pp_epi_k)
+    // register epilogue (see pp_epi_k): no LDS image, no barrier
 #if DEMO_EPI_ABLATE == 2
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-    pp_epi(p, acc, m0 + wr * 128 + frow, n0 + wc * 64 + (lane >> 4) * 8, coff, bias, lds_off(smem + A_BYTES), m0, n0, lane, wave);
+    pp_epi(p, acc, m0 + wr * 128 + frow, n0 + wc * 64 + g4 * 8, coff, bias, smem, m0, n0);
 #endif
-    if (!more) return;
-    lds_done_barrier();                             // every wave has read its rows of the image: the ring may be re-staged
-    bid = nbid; m0 = m0n; n0 = n0n;
-    a0_staged = true;
-    continue;
+    return;
   }
-  const int64_t coff = z * p.sC;
-  const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
-  const int g4 = lane >> 4;
   float* ct = reinterpret_cast<float*>(smem);
   const int c = threadIdx.x & 31;                   // this thread's 8-column chunk, the same in every pass
   float4 bz0 = make_float4(0.f, 0.f, 0.f, 0.f), bz1 = bz0;
@@ -1116,8 +1082,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
     __syncthreads();
     epi_rows<8, 16, BN, 2>(p, ct, threadIdx.x >> 5, m0 + half * 128, n0 + c * 8, c, bz0, bz1, coff, epre, have_epre);   // 128 rows x 32 chunks
   }
-  return;
-  }   // for (;;)
 }
 
 // ---- 256 x 128 "twin" kernel: TWO workgroups per CU -----------------------------------------------------------------------------
@@ -1269,10 +1233,12 @@ int demo_gemm_bf16_eligible(const demo_gemm_desc& d) {
 static int g_force_tile = 0;   // test/bench hook: 128 or 256 forces a configuration, 0 = heuristic
 static int g_pp_reg_epi = 1;   // 256^2 kernel: 1 = register epilogue over permuted weight rows, 0 = LDS-staged row-major epilogue
 static int g_pp_min_eff_pct = 70;
-static int g_persist = 1;      // 256^2 kernel: persistent walk (256 workgroups) where the shape allows
-extern "C" int demo_gemm_set_persist(int on) { g_persist = on ? 1 : 0; return 0; }
+static int g_dephase = 0;
+extern "C" int demo_gemm_set_dephase(int units) { g_dephase = units < 0 ? 0 : units; return 0; }
 static int g_epi_stage = 1;
 extern "C" int demo_gemm_set_epi_stage(int on) { g_epi_stage = on ? 1 : 0; return 0; }
+static int g_colslice = 0;     // 0 = heuristic, 1 = off, 2 / 4 / 8 = forced where ntn divides
+extern "C" int demo_gemm_set_colslice(int s) { g_colslice = s; return 0; }
 extern "C" int demo_gemm_store_policy(void) { return DEMO_STORE_POL; }
 extern "C" int demo_gemm_set_pp_min_fill(int pct) { g_pp_min_eff_pct = pct; return 0; }
 void demo_gemm_tn_force(int t);
@@ -1402,7 +1368,8 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
   p.pre_out = d.pre_out;
   p.pre_out_kind = d.pre_out ? d.pre_out_kind : 0;
   p.dtRes = d.residual ? d.dtRes : 0;
-  p.persist = 0;
+  p.dephase = g_dephase;
+  p.colslice = 0;
   p.epi_stage = g_epi_stage;
   p.M = d.M; p.N = d.N; p.K = d.K;
   p.lda = d.a_rs; p.ldb = d.b_rs; p.ldc = d.c_rs;
@@ -1440,10 +1407,13 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
       p.group_m = 32 / p.ntn < 1 ? 1 : (32 / p.ntn > 8 ? 8 : 32 / p.ntn);      // (2..8 measured within 1 % of each other)
       {
         unsigned grid = (unsigned)(p.ntm * p.ntn);
-        p.persist = 0;
-        if (g_persist && g_pp_reg_epi && nb == 1 && grid > 256 && (d.K / BK) % 3 == 0) {      // (nk % 3 == 0: A slot 0 is free at the end of a tile)
-          p.persist = 256;
-          grid = 256;
+        p.colslice = 0;
+        const int S = g_colslice;
+        if (S > 1 && 8 % S == 0 && p.ntn % S == 0 && nb == 1) {
+          const int c = p.ntn / S, R = 8 / S;
+          p.colslice = S;
+          p.group_m = 32 / c < 1 ? 1 : (32 / c > 8 ? 8 : 32 / c);
+          grid = 8u * (unsigned)(cdiv64(p.ntm, R) * c);
         }
         if (g_pp_reg_epi)
           hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<true>, dim3(grid, (unsigned)nb), dim3(512), 0, s, p);

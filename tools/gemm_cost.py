@@ -68,9 +68,8 @@ TILE = int(os.environ.get("DEMO_FORCE_TILE", "2566"))
 tag = f"{tag}:{TILE}"
 lib.demo_gemm_force_tile(TILE)
 lib.demo_gemm_set_split(0)
-for _v in ("DEMO_GEMM_PERSIST", "DEMO_GEMM_EPI_STAGE", "DEMO_GEMM_SPLIT_OVERLAP"):
-    if _v in os.environ:
-        tag += ":" + _v[10:].lower() + os.environ[_v]
+if "DEMO_GEMM_DEPHASE" in os.environ:
+    tag += ":dephase" + os.environ["DEMO_GEMM_DEPHASE"]
 try:
     for name, fl, fn in cases:
         t = timeit(fn)
