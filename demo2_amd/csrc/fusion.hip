@@ -91,8 +91,8 @@ __global__ __launch_bounds__(512) void hdm_softmax_pool_kernel(const float* __re
   for (int h = 0; h < HH_MAX; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (split < nsplit) {
     // U tokens per step, all U loads requested before the first is used: a thread walks ~Lk / nsplit tokens (97 at Lk = 387), and one
-    // dependent HBM/L2 round trip per token made this kernel 99 us at B = 1 (U = 8 on small grids; on chip-filling grids the other
-    // workgroups hide the latency and the extra registers cost occupancy: 147 -> 214 us at B = 128, so U = 1 there)
+    // dependent HBM/L2 round trip per token made this kernel 99 us at B = 1 (U = 8 on small grids: 130 VGPRs, one workgroup per CU; on chip-filling
+    // grids that occupancy costs more than it hides -- 147 -> 214 us at B = 128 -- so U = 4 there: 96 VGPRs, two workgroups per CU, 122 us)
     for (int lk0 = split; lk0 < Lk; lk0 += U * nsplit) {
       typename io<T>::raw4 xr[U];
 #pragma unroll
@@ -197,7 +197,7 @@ extern "C" int demo_hdm_softmax_pool(const float* S, int64_t ldS, const void* to
   dim3 grid(Bs, 7);
   const bool small = (int64_t)Bs * 7 < 512;
 #define HDM_POOL(T_, U_) hipLaunchKernelGGL((hdm_softmax_pool_kernel<T_, U_>), grid, dim3(512), shm, s, S, ldS, (const T_*)tokens, pooled, psum, probs, probs_post, Bs, L, C, Hh, p_drop, seed, seed_dev)
-  if (dt == DEMO_BF16) { if (small) HDM_POOL(bf16_t, 8); else HDM_POOL(bf16_t, 1); }
+  if (dt == DEMO_BF16) { if (small) HDM_POOL(bf16_t, 8); else HDM_POOL(bf16_t, 4); }
   else { if (small) HDM_POOL(float, 8); else HDM_POOL(float, 1); }
 #undef HDM_POOL
   DEMO_LAUNCH_CHECK("demo_hdm_softmax_pool");
