@@ -8,11 +8,13 @@ export TMPDIR=/tmp
 O=gpurun_out/prof
 rm -rf $O; mkdir -p $O
 step() { echo "== $*" | tee -a $O/log.txt; }
-step bench default;        python bench.py > $O/bench_default.json 2> $O/bench_default.err || echo FAILED
-step kernel stats;         rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o t -- python3 bench.py > $O/bench_default_under_rocprof.json 2> $O/stats.err || echo FAILED
 step pmc fetch;            rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_F -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_F.log 2>&1 || echo FAILED
 step pmc write;            rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_W -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_W.log 2>&1 || echo FAILED
 python tools/pmc_traffic.py $O/pmc_F $O/pmc_W > $O/hbm_traffic_pmc.json || echo FAILED
+# the bench lines below read roofline.traffic from the newest profiles/r*_hbm_traffic_pmc.json: publish this pass's file first (ROUND=rNN)
+cp $O/hbm_traffic_pmc.json profiles/${ROUND:-r02}_hbm_traffic_pmc.json
+step bench default;        python bench.py > $O/bench_default.json 2> $O/bench_default.err || echo FAILED
+step kernel stats;         rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o t -- python3 bench.py > $O/bench_default_under_rocprof.json 2> $O/stats.err || echo FAILED
 step pmc l2 a;             rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_BUBBLE_sum --output-format csv -d $O/pmc_l2a -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_l2a.log 2>&1 || echo FAILED
 step pmc l2 b;             rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum TCC_REQ_sum TCC_READ_sum --output-format csv -d $O/pmc_l2b -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_l2b.log 2>&1 || echo FAILED
 python tools/pmc_l2.py $O/pmc_l2a $O/pmc_l2b > $O/l2_pmc.json || echo FAILED
