@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the training step from a captured hipGraph (single GPU); measured equal to eager launches")
+                    help="replay the step from a captured hipGraph (single GPU): the training step measured equal to eager launches; the eval forward "
+                         "(--mode fwd) is host-bound at small batches and gains")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--fusion", choices=["atmoe", "dgaf"], default="atmoe",
                     help="atmoe: the headline PIFE -> HDM -> ATMoE model; dgaf: the DeMo class's DGAF-V3 head (SURVEY 8(f) row 3, a side "
@@ -363,10 +364,16 @@ def main():
     else:
         model.eval()
 
-        def step():
+        def eager_step():
             with torch.no_grad():
                 model(x, cam_label=cam, return_pattern=3)
-        eager_step = step
+        step = eager_step
+        if a.graph and world == 1:             # small-batch serving: replay the forward from a captured hipGraph (host-bound at B = 1)
+            from demo2_amd.modeling.eval_graph import EvalGraph
+            replay = EvalGraph(model, B, img_h, img_w, return_pattern=3)
+
+            def step():
+                replay(x, cam_label=cam)
 
     def fence():
         if world > 1:
@@ -431,7 +438,7 @@ def main():
                                     + ("train step fwd+bwd, " if mode == "train" else "eval forward, ")
                                     + f"3x({B},3,{img_h},{img_w}) per GPU, random-init weights"),
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}", "mode": mode,
-                       "launch": "hipGraph replay" if (mode == "train" and stepper.use_graph) else "eager",
+                       "launch": "hipGraph replay" if ((mode == "train" and stepper.use_graph) or (mode == "fwd" and a.graph and world == 1)) else "eager",
                        "input": "pinned host memory, copied every step (PCIe-inclusive)" if (mode == "train" and a.host_input)
                        else "resident in HBM"},
             "model_tflops": round(val * flop_per_triplet / 1e12, 1),

@@ -84,6 +84,40 @@ def test_single_sample_eval():
     torch.testing.assert_close(got.cpu(), want, rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_eval_graph_replay_equals_eager_forward(dtype):
+    """EvalGraph (hipGraph replay of the inference forward, small-batch serving): the eager forward's result for every batch fed through
+    the captured graph (to the run-to-run spread of the split-K fp32 atomics: 1e-5), re-captured after a parameter update, same
+    IndexError for an out-of-range camera id."""
+    from demo2_amd.modeling.eval_graph import EvalGraph
+    m, sd = build(small_cfg("clip"), 11, 3, dtype=dtype)
+    g = EvalGraph(m, 2, 64, 32, return_pattern=3)
+    for seed in (3, 4, 5):
+        x, cam = synth_batch(2, 64, 32, 3, seed=seed)
+        xd = {k: v.to(DEV) for k, v in x.items()}
+        with torch.no_grad():
+            want = m(xd, cam_label=cam.to(DEV), return_pattern=3)
+        got = g(xd, cam_label=cam.to(DEV))
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    if dtype == torch.float32:
+        torch.testing.assert_close(got.cpu(), O.model_forward(sd, spec_of(m), x, cam, return_pattern=3), rtol=2e-4, atol=2e-4)
+    with torch.no_grad():                                   # a parameter update invalidates the capture
+        next(p for n, p in m.named_parameters() if n.endswith("q_.weight")).mul_(1.5)
+    with torch.no_grad():
+        want = m(xd, cam_label=cam.to(DEV), return_pattern=3)
+    assert (want - got).abs().max() > 1e-3
+    torch.testing.assert_close(g(xd, cam_label=cam.to(DEV)), want, rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError):
+        g({k: v[:1] for k, v in xd.items()}, cam_label=cam[:1].to(DEV))
+    bad = cam.clone()
+    bad[0] = 7                                              # 3 cameras
+    g(xd, cam_label=bad.to(DEV))
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        g(xd, cam_label=cam.to(DEV))
+    g(xd, cam_label=cam.to(DEV))                            # the report was consumed: the path works again
+
+
 @pytest.mark.parametrize("name,classes,cams,size", [("RGBNT201", 171, 4, (256, 128)), ("RGBNT100", 50, 8, (128, 256))])
 def test_full_size_eval_fp32_and_bf16(name, classes, cams, size):
     """BASELINE configs A and B at full model size (98.8 M parameters), B=2."""
