@@ -69,23 +69,26 @@ __global__ __launch_bounds__(512) void hdm_softmax_pool_kernel(const float* __re
         const uint32_t u = rng_hash(seed, ((uint64_t)(b * 7 + br) * Hh + h) * L3 + i);
         p = (u >= thresh) ? p * keep_scale : 0.f;
       }
-      if (probs) probs[((int64_t)(b * 7 + br) * Hh + h) * L3 + i] = ph[i] * inv;     // softmax BEFORE dropout (backward needs it)
+      if (probs && blockIdx.z == 0) probs[((int64_t)(b * 7 + br) * Hh + h) * L3 + i] = ph[i] * inv;     // softmax BEFORE dropout (backward needs it)
       ph[i] = p;
       kept += p;
-      if (probs_post) probs_post[((int64_t)(b * 7 + br) * Hh + h) * L3 + i] = p;
+      if (probs_post && blockIdx.z == 0) probs_post[((int64_t)(b * 7 + br) * Hh + h) * L3 + i] = p;
     }
     for (int i = Lk + lane; i < L3; i += 64) {
-      if (probs) probs[((int64_t)(b * 7 + br) * Hh + h) * L3 + i] = 0.f;
-      if (probs_post) probs_post[((int64_t)(b * 7 + br) * Hh + h) * L3 + i] = 0.f;
+      if (probs && blockIdx.z == 0) probs[((int64_t)(b * 7 + br) * Hh + h) * L3 + i] = 0.f;
+      if (probs_post && blockIdx.z == 0) probs_post[((int64_t)(b * 7 + br) * Hh + h) * L3 + i] = 0.f;
     }
     kept = wave_sum(kept);
-    if (lane == 0 && psum) psum[(int64_t)(b * 7 + br) * Hh + h] = kept;
+    if (lane == 0 && psum && blockIdx.z == 0) psum[(int64_t)(b * 7 + br) * Hh + h] = kept;
   }
   __syncthreads();
   // ---- phase 3: pooled[h][c] = sum_lk P[h][lk] * X[lk][c] -------------------------------------------
-  const int ngroups = C >> 2;                            // channel groups of 4
+  // gridDim.z channel chunks (small grids: the (sample, branch) workgroups alone leave most CUs idle -- 7 workgroups at B = 1 -- so the
+  // pooling of a branch is cut across z; phases 1-2 are repeated per chunk, only chunk 0 writes the probabilities)
+  const int ngroups = (C >> 2) / gridDim.z;              // channel groups of 4 in this chunk
   const int nsplit = blockDim.x / ngroups;               // >= 1 (C <= 1024)
-  const int grp = threadIdx.x % ngroups, split = threadIdx.x / ngroups;
+  const int gl = threadIdx.x % ngroups, split = threadIdx.x / ngroups;
+  const int grp = blockIdx.z * ngroups + gl;
   float4 acc[HH_MAX];
 #pragma unroll
   for (int h = 0; h < HH_MAX; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(512) void hdm_softmax_pool_kernel(const float* __re
         __syncthreads();
         if (split == 0) {
           for (int sp = 1; sp < nsplit; ++sp) {
-            const float4 o = *reinterpret_cast<const float4*>(red + (sp * ngroups + grp) * 4);
+            const float4 o = *reinterpret_cast<const float4*>(red + (sp * ngroups + gl) * 4);
             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
           }
         }
@@ -194,8 +197,10 @@ extern "C" int demo_hdm_softmax_pool(const float* S, int64_t ldS, const void* to
   const size_t shm = sizeof(float) * ((size_t)Hh * 3 * L + 512 * 4);
   DEMO_REQUIRE(shm <= 64 * 1024, "demo_hdm_softmax_pool: L=%d too long", L);
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(Bs, 7);
   const bool small = (int64_t)Bs * 7 < 512;
+  int nz = 1;                                          // channel chunks: fill ~256 CUs on small grids (a chunk keeps >= 16 channel groups)
+  while ((int64_t)Bs * 7 * nz < 256 && nz < 8 && (C / 4) % (nz * 2) == 0 && (C / 4) / (nz * 2) >= 16 && 512 % ((C / 4) / (nz * 2)) == 0) nz *= 2;
+  dim3 grid(Bs, 7, nz);
 #define HDM_POOL(T_, U_) hipLaunchKernelGGL((hdm_softmax_pool_kernel<T_, U_>), grid, dim3(512), shm, s, S, ldS, (const T_*)tokens, pooled, psum, probs, probs_post, Bs, L, C, Hh, p_drop, seed, seed_dev)
   if (dt == DEMO_BF16) { if (small) HDM_POOL(bf16_t, 8); else HDM_POOL(bf16_t, 4); }
   else { if (small) HDM_POOL(float, 8); else HDM_POOL(float, 1); }
