@@ -513,6 +513,156 @@ __global__ __launch_bounds__(256, 2) void layernorm_bwd_hw_kernel(const bf16_t* 
   }
 }
 
+// LayerNorm backward on all-bf16 streams, ONE WAVE per row, D = 512 * N8 + 256 * N4 (768: N8 = N4 = 1): lane l owns columns
+// [8l, 8l + 8) of every 512-column block (a 16-B access) and [512 N8 + 4l, + 4) of the 256-column tail (an 8-B access).  12 columns per
+// lane at D = 768 instead of the half-wave form's 24: 24 column accumulators + 12 weights per lane leave room for TWO rows of prefetch
+// and four waves per SIMD, which the half-wave form (238 VGPRs, one row ahead, two waves per SIMD) does not have.
+template <int N8, int N4>
+__global__ __launch_bounds__(256, 3) void layernorm_bwd_w_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                 const float* __restrict__ w, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
+                                                                 bf16_t* __restrict__ out, float* __restrict__ dw, float* __restrict__ db,
+                                                                 float* __restrict__ part, int M, int rows_per_block) {
+  constexpr int D = 512 * N8 + 256 * N4, NCOL = 8 * N8 + 4 * N4, T0 = 512 * N8;
+  __shared__ float red[4][2][D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float wv[NCOL], adw[NCOL], adb[NCOL];
+#pragma unroll
+  for (int i = 0; i < N8; ++i) {
+    const float4 a = *reinterpret_cast<const float4*>(w + 512 * i + 8 * lane), b = *reinterpret_cast<const float4*>(w + 512 * i + 8 * lane + 4);
+    wv[8 * i + 0] = a.x; wv[8 * i + 1] = a.y; wv[8 * i + 2] = a.z; wv[8 * i + 3] = a.w;
+    wv[8 * i + 4] = b.x; wv[8 * i + 5] = b.y; wv[8 * i + 6] = b.z; wv[8 * i + 7] = b.w;
+  }
+  if constexpr (N4) {
+    const float4 a = *reinterpret_cast<const float4*>(w + T0 + 4 * lane);
+    wv[8 * N8 + 0] = a.x; wv[8 * N8 + 1] = a.y; wv[8 * N8 + 2] = a.z; wv[8 * N8 + 3] = a.w;
+  }
+#pragma unroll
+  for (int e = 0; e < NCOL; ++e) adw[e] = adb[e] = 0.f;
+  struct Row {                                       // one row of the three operands, still packed
+    uint4 x8[N8 ? N8 : 1], d8[N8 ? N8 : 1], p8[N8 ? N8 : 1];
+    uint2 x4, d4, p4;
+    float mu, rs;
+  };
+  const float inv_d = 1.f / (float)D;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int rend = min(M, r0 + rows_per_block);
+  const int iters = (rend - r0 + 3) >> 2;            // workgroup-uniform; a wave takes rows r0 + wave + 4 j
+  auto fetch = [&](Row& r, int row) {
+    const bool ok = row < rend;
+    const int64_t o = (int64_t)(ok ? row : r0) * D;
+    r.mu = mean[ok ? row : r0];
+    r.rs = ok ? rstd[row] : 0.f;
+    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+    const uint2 z2 = make_uint2(0u, 0u);
+#pragma unroll
+    for (int i = 0; i < N8; ++i) {
+      r.x8[i] = ok ? *reinterpret_cast<const uint4*>(x + o + 512 * i + 8 * lane) : z4;
+      r.d8[i] = ok ? *reinterpret_cast<const uint4*>(dy + o + 512 * i + 8 * lane) : z4;
+      r.p8[i] = (ok && dres) ? *reinterpret_cast<const uint4*>(dres + o + 512 * i + 8 * lane) : z4;
+    }
+    if constexpr (N4) {
+      r.x4 = ok ? *reinterpret_cast<const uint2*>(x + o + T0 + 4 * lane) : z2;
+      r.d4 = ok ? *reinterpret_cast<const uint2*>(dy + o + T0 + 4 * lane) : z2;
+      r.p4 = (ok && dres) ? *reinterpret_cast<const uint2*>(dres + o + T0 + 4 * lane) : z2;
+    }
+  };
+  auto unpack = [&](const Row& r, float (&xf)[NCOL], float (&df)[NCOL]) {
+#pragma unroll
+    for (int i = 0; i < N8; ++i) {
+      float a[8], b[8];
+      bf16x8_unpack(r.x8[i], a);
+      bf16x8_unpack(r.d8[i], b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { xf[8 * i + e] = a[e]; df[8 * i + e] = b[e]; }
+    }
+    if constexpr (N4) {
+      xf[8 * N8 + 0] = __uint_as_float(r.x4.x << 16); xf[8 * N8 + 1] = __uint_as_float(r.x4.x & 0xffff0000u);
+      xf[8 * N8 + 2] = __uint_as_float(r.x4.y << 16); xf[8 * N8 + 3] = __uint_as_float(r.x4.y & 0xffff0000u);
+      df[8 * N8 + 0] = __uint_as_float(r.d4.x << 16); df[8 * N8 + 1] = __uint_as_float(r.d4.x & 0xffff0000u);
+      df[8 * N8 + 2] = __uint_as_float(r.d4.y << 16); df[8 * N8 + 3] = __uint_as_float(r.d4.y & 0xffff0000u);
+    }
+  };
+  auto work = [&](const Row& r, int row) {
+    float xf[NCOL], df[NCOL];
+    unpack(r, xf, df);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < NCOL; ++e) {
+      xf[e] = (xf[e] - r.mu) * r.rs;                  // x-hat (masked rows: dy = 0, rstd = 0)
+      const float g = df[e] * wv[e];
+      s1 += g;
+      s2 = fmaf(g, xf[e], s2);
+    }
+    s1 = wave_sum(s1) * inv_d;
+    s2 = wave_sum(s2) * inv_d;
+    float o[NCOL];
+#pragma unroll
+    for (int e = 0; e < NCOL; ++e) {
+      adw[e] = fmaf(df[e], xf[e], adw[e]);
+      adb[e] += df[e];
+      o[e] = r.rs * (df[e] * wv[e] - s1 - xf[e] * s2);
+    }
+    if (row < rend) {
+#pragma unroll
+      for (int i = 0; i < N8; ++i) {
+        float pf[8];
+        bf16x8_unpack(r.p8[i], pf);
+        uint4 q;
+        q.x = pack_bf16x2(o[8 * i + 0] + pf[0], o[8 * i + 1] + pf[1]); q.y = pack_bf16x2(o[8 * i + 2] + pf[2], o[8 * i + 3] + pf[3]);
+        q.z = pack_bf16x2(o[8 * i + 4] + pf[4], o[8 * i + 5] + pf[5]); q.w = pack_bf16x2(o[8 * i + 6] + pf[6], o[8 * i + 7] + pf[7]);
+        *reinterpret_cast<uint4*>(out + (int64_t)row * D + 512 * i + 8 * lane) = q;
+      }
+      if constexpr (N4) {
+        const float p0 = __uint_as_float(r.p4.x << 16), p1 = __uint_as_float(r.p4.x & 0xffff0000u);
+        const float p2 = __uint_as_float(r.p4.y << 16), p3 = __uint_as_float(r.p4.y & 0xffff0000u);
+        uint2 q;
+        q.x = pack_bf16x2(o[8 * N8 + 0] + p0, o[8 * N8 + 1] + p1);
+        q.y = pack_bf16x2(o[8 * N8 + 2] + p2, o[8 * N8 + 3] + p3);
+        *reinterpret_cast<uint2*>(out + (int64_t)row * D + T0 + 4 * lane) = q;
+      }
+    }
+  };
+  // two rows ahead: ra is worked while rb and the next ra are in flight
+  Row ra, rb;
+  fetch(ra, r0 + wave);
+  fetch(rb, r0 + wave + 4);
+  for (int it = 0; it < iters; it += 2) {
+    const int row = r0 + wave + 4 * it;
+    Row rc;
+    fetch(rc, row + 8);
+    work(ra, row);
+    ra = rc;
+    if (it + 1 < iters) {
+      Row rd;
+      fetch(rd, row + 12);
+      work(rb, row + 4);
+      rb = rd;
+    }
+  }
+  if (!dw && !db) return;
+  // column sums: waves through LDS, one partial row per workgroup
+#pragma unroll
+  for (int i = 0; i < N8; ++i) {
+    *reinterpret_cast<float4*>(&red[wave][0][512 * i + 8 * lane]) = make_float4(adw[8 * i], adw[8 * i + 1], adw[8 * i + 2], adw[8 * i + 3]);
+    *reinterpret_cast<float4*>(&red[wave][0][512 * i + 8 * lane + 4]) = make_float4(adw[8 * i + 4], adw[8 * i + 5], adw[8 * i + 6], adw[8 * i + 7]);
+    *reinterpret_cast<float4*>(&red[wave][1][512 * i + 8 * lane]) = make_float4(adb[8 * i], adb[8 * i + 1], adb[8 * i + 2], adb[8 * i + 3]);
+    *reinterpret_cast<float4*>(&red[wave][1][512 * i + 8 * lane + 4]) = make_float4(adb[8 * i + 4], adb[8 * i + 5], adb[8 * i + 6], adb[8 * i + 7]);
+  }
+  if constexpr (N4) {
+    *reinterpret_cast<float4*>(&red[wave][0][T0 + 4 * lane]) = make_float4(adw[8 * N8], adw[8 * N8 + 1], adw[8 * N8 + 2], adw[8 * N8 + 3]);
+    *reinterpret_cast<float4*>(&red[wave][1][T0 + 4 * lane]) = make_float4(adb[8 * N8], adb[8 * N8 + 1], adb[8 * N8 + 2], adb[8 * N8 + 3]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * D; c += 256) {
+    const int k = c >= D ? 1 : 0, col = c - k * D;
+    const float v = (red[0][k][col] + red[1][k][col]) + (red[2][k][col] + red[3][k][col]);
+    if (part) part[(int64_t)blockIdx.x * 2 * D + c] = v;
+    else if (k == 0) { if (dw) atomicAdd(&dw[col], v); }
+    else if (db) atomicAdd(&db[col], v);
+  }
+}
+
 // Backward, row-owner form (any D up to 2048): one wave per row for dx; dw/db accumulated per block in LDS then atomically
 // added into fp32 dw/db (D floats each; D*gridDim atomics spread over D addresses).
 // NV = float4 per lane (compile time: D = 768 -> 3), so that only the registers a row needs are allocated and 8 waves per
@@ -779,7 +929,7 @@ extern "C" int demo_layernorm_fwd(const float* x, const float* w, const float* b
   return 0;
 }
 
-static int g_ln_lp8 = 1;      // tuning hook: 0 = the wave-per-row / 4-column kernels also for all-bf16 streams, 2 = backward in the 128-thread 8-column form
+static int g_ln_lp8 = 1;      // tuning hook: 0 = the wave-per-row / 4-column kernels also for all-bf16 streams, 2 = backward in the 128-thread 8-column form, 3 = backward in the half-wave form
 extern "C" int demo_layernorm_set_lp8(int on) { g_ln_lp8 = on < 0 ? 0 : on; return 0; }
 
 extern "C" int demo_layernorm_add_fwd(const void* x, int32_t dtX, const void* add, int32_t dtAdd, void* xsum_out, const float* w, const float* b,
@@ -871,17 +1021,26 @@ extern "C" int demo_layernorm_bwd_lp(const void* dy, int32_t dtDy, const void* x
   DEMO_REQUIRE(D % 4 == 0 && D <= 1024, "demo_layernorm_bwd_lp: D=%d unsupported (<= 1024)", D);
   DEMO_REQUIRE(dy && x && w && mean && rstd && dx_bf16 && M > 0, "demo_layernorm_bwd_lp: null operand");
   hipStream_t s = (hipStream_t)stream;
-  const bool hw_form = dtDy == DEMO_BF16 && dtX == DEMO_BF16 && D % 8 == 0 && D <= 768 && g_ln_lp8 == 1;      // all-bf16 streams: half a wave per row
+  const bool w_form = dtDy == DEMO_BF16 && dtX == DEMO_BF16 && (D == 768 || D == 512) && g_ln_lp8 == 1;      // wave per row, two rows ahead
+  const bool hw_form = dtDy == DEMO_BF16 && dtX == DEMO_BF16 && D % 8 == 0 && D <= 768 && (g_ln_lp8 == 3 || (g_ln_lp8 == 1 && !w_form));      // all-bf16 streams: half a wave per row
   // half-wave form: two 256-thread workgroups fit a CU (238 VGPRs), so the grid is ONE round of 512 workgroups where M allows (774 workgroups
   // of 64 rows ran as 1.5 rounds: the second half empty)
-  const int rows_per_block = hw_form ? (int)(cdiv64(M, 512) < 8 ? 8 : cdiv64(M, 512)) : (M >= 16384 ? 32 : 16);
+  // wave form: three 256-thread workgroups fit a CU (152 VGPRs) -> ONE round of 768 workgroups where M allows
+  const int rows_per_block = w_form ? (int)(cdiv64(M, 768) < 8 ? 8 : cdiv64(M, 768)) : hw_form ? (int)(cdiv64(M, 512) < 8 ? 8 : cdiv64(M, 512)) : (M >= 16384 ? 32 : 16);
   const int nblk = (int)cdiv64(M, rows_per_block);
   float* part = (workspace && workspace_elems >= (int64_t)nblk * 2 * D && (dw || db)) ? workspace : nullptr;
   const dim3 blk((unsigned)(cdiv64(D, 256) * 64));
 #define LN_LP(TDY_, TX_)                                                                                                               \
   hipLaunchKernelGGL((layernorm_bwd_cols_kernel<TDY_, 4, false, true, TX_>), dim3((unsigned)nblk), blk, 0, s, (const TDY_*)dy, (const TX_*)x, w, \
                      mean, rstd, (float*)nullptr, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block, (const bf16_t*)dres_bf16)
-  if (hw_form) {                                     // (wider rows spill at four chunks per lane: they keep the 128-thread form)
+  if (w_form) {
+    if (D == 768)
+      hipLaunchKernelGGL((layernorm_bwd_w_kernel<1, 1>), dim3((unsigned)nblk), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, w, mean, rstd,
+                         (const bf16_t*)dres_bf16, (bf16_t*)dx_bf16, dw, db, part, M, rows_per_block);
+    else
+      hipLaunchKernelGGL((layernorm_bwd_w_kernel<1, 0>), dim3((unsigned)nblk), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, w, mean, rstd,
+                         (const bf16_t*)dres_bf16, (bf16_t*)dx_bf16, dw, db, part, M, rows_per_block);
+  } else if (hw_form) {                              // (wider rows spill at four chunks per lane: they keep the 128-thread form)
     hipLaunchKernelGGL(layernorm_bwd_hw_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, w, mean, rstd,
                        (const bf16_t*)dres_bf16, (bf16_t*)dx_bf16, dw, db, part, M, D, rows_per_block);
   } else if (dtDy == DEMO_BF16 && dtX == DEMO_BF16 && D % 8 == 0 && g_ln_lp8)      // (hook value 2) the 128-thread form: 8 columns per thread

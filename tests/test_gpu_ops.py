@@ -255,7 +255,7 @@ def test_layernorm_add_fwd(xdt):
     torch.testing.assert_close(y3.float().cpu(), O.layer_norm(x.float(), w, b, 1e-5), rtol=1e-2, atol=1e-2)
 
 
-@pytest.mark.parametrize("M,D", [(300, 768), (2500, 768), (37, 128)])
+@pytest.mark.parametrize("M,D", [(300, 768), (2500, 768), (37, 128), (70, 512), (9000, 512)])
 def test_layernorm_bwd_lp_stream(M, D):
     """demo_layernorm_bwd_lp: bf16(dres + LayerNorm-backward(dy)) with the running gradient in bf16, no fp32 stream; dw/db as usual;
     in place (output == running gradient) as the single-stream schedule uses it."""
@@ -275,14 +275,14 @@ def test_layernorm_bwd_lp_stream(M, D):
     torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-4, atol=1e-3)
     out2 = ops.layernorm_bwd_lp(dy.to(DEV), x.detach().to(DEV), w.detach().to(DEV), mean, rstd, None, torch.empty(M, D, device=DEV, dtype=torch.bfloat16))
     torch.testing.assert_close(out2.float().cpu(), x.grad.bfloat16().float(), rtol=1e-2, atol=1e-2)
-    # bf16 residual stream: x itself is bf16 (statistics taken from the rounded values) -- half a wave per row (1), the 128-thread 8-column form (2), the 4-column one (0)
+    # bf16 residual stream: x itself is bf16 (statistics taken from the rounded values) -- a wave per row with two rows ahead (1), half a wave per row (3), the 128-thread 8-column form (2), the 4-column one (0)
     from demo2_amd import _lib
     xb = (rnd(M, D, seed=11) + 0.3).bfloat16()
     xr = xb.float().requires_grad_(True)
     O.layer_norm(xr, w.detach(), b.detach(), 1e-5).backward(dy.float())
     _, mean, rstd = ops.layernorm_add_fwd(xb.to(DEV), None, w.detach().to(DEV), b.detach().to(DEV), 1e-5, save=True)
     wref = (dy.float() * ((xr.detach() - xr.detach().mean(1, keepdim=True)) * torch.rsqrt(xr.detach().var(1, unbiased=False, keepdim=True) + 1e-5))).sum(0)
-    for lp8 in (1, 2, 0):
+    for lp8 in (1, 3, 2, 0):
         _lib.load().demo_layernorm_set_lp8(lp8)
         try:
             yv, mv, rv = ops.layernorm_add_fwd(xb.to(DEV), None, w.detach().to(DEV), b.detach().to(DEV), 1e-5, save=True)     # forward: half-wave / wave per row
