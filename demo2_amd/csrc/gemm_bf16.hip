@@ -178,6 +178,12 @@ __device__ __forceinline__ uint4 f32x8_to_bf16(const float (&v)[8]) {
 #define DEMO_EPI_ABLATE 0
 #endif
 // phases per K-tile of the 256^2 kernels' main loops: 2 (32 MFMAs between barriers) or 4 (16, the round-1 form; A/B variant)
+// DEMO_FEED_ABLATE (measurement builds only, never the product; results are wrong by construction): 1 = the 256^2 NT main loop issues
+// no LDS-DMA after its prologue (what the loop costs with NO operand feed), 2 = every workgroup stages the operands of tile (0, 0)
+// (the same instructions, every load an L2 hit): separates the cost of issuing the feed from the cost of its misses
+#ifndef DEMO_FEED_ABLATE
+#define DEMO_FEED_ABLATE 0
+#endif
 #ifndef DEMO_PP_PHASES
 #define DEMO_PP_PHASES 2
 #endif
@@ -980,13 +986,25 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
     lds_read2(b1f[1], lb + 4096 + foff1);
     lds_read4(af[0], la + foff0);
     lds_read4(af[1], la + foff1);
+#if DEMO_FEED_ABLATE == 1
+    if (has1 && p.K < 0) stage_tile<BN, NW, REG_EPI>(B, p.ldb, n0, p.N, (t + 1) * BK, smem_b + (t & 1) * B_BYTES, wave, lane);
+#elif DEMO_FEED_ABLATE == 2
+    if (has1) stage_tile<BN, NW, REG_EPI>(B, p.ldb, 0, p.N, (t + 1) * BK, smem_b + (t & 1) * B_BYTES, wave, lane);
+#else
     if (has1) stage_tile<BN, NW, REG_EPI>(B, p.ldb, n0, p.N, (t + 1) * BK, smem_b + (t & 1) * B_BYTES, wave, lane);
+#endif
     PP_MFMA32(0);
     __builtin_amdgcn_s_barrier();
     // ---- P2
     lds_read4(af[0], la + 8192 + foff0);
     lds_read4(af[1], la + 8192 + foff1);
+#if DEMO_FEED_ABLATE == 1
+    if (has2 && p.K < 0) stage_tile<BM, NW, false, DEMO_A_AUX>(A, p.lda, m0, p.M, (t + 2) * BK, smem + sa2 * A_BYTES, wave, lane);
+#elif DEMO_FEED_ABLATE == 2
+    if (has2) stage_tile<BM, NW, false, DEMO_A_AUX>(A, p.lda, 0, p.M, (t + 2) * BK, smem + sa2 * A_BYTES, wave, lane);
+#else
     if (has2) stage_tile<BM, NW, false, DEMO_A_AUX>(A, p.lda, m0, p.M, (t + 2) * BK, smem + sa2 * A_BYTES, wave, lane);
+#endif
     if (wr == 1) {
       if (has2) wait_vmcnt<4>();
       else if (has1) wait_vmcnt<0>();
