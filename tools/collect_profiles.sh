@@ -29,6 +29,7 @@ step fwd B=1;              python bench.py --mode fwd --batch 1 --steps 200 --wa
 step gemm cost;            python tools/gemm_cost.py > $O/gemm_cost.txt 2>&1 || echo FAILED
 step attention;            python tools/bench_attn.py > $O/bench_attn.txt 2>&1 || echo FAILED
 step layernorm;            python tools/bench_ln.py > $O/bench_ln.txt 2>&1 || echo FAILED
+[ -x tools/probes/store_probe ] || hipcc --offload-arch=gfx950 -O3 tools/probes/store_probe.hip -o tools/probes/store_probe
 step store probe;          tools/probes/store_probe > $O/store_probe.txt 2>&1 || echo FAILED
 step eval latency;         bash tools/eval_latency.sh > $O/eval_latency.txt 2>&1 || echo FAILED
 step eval kernel stats;    bash tools/eval_profile.sh > $O/eval_profile.log 2>&1 || echo FAILED
