@@ -81,11 +81,15 @@ def gemm_roofline(model, step_fn):
         e1.record()
         nb = d.batch1 * d.batch2
         szc = 4 if d.dtC == _lib.F32 else 2
-        nbytes = nb * (2 * d.M * d.K + 2 * d.N * d.K + d.M * d.N * szc * (2 if d.pre_out else 1)
+        sz_pre_out = 0 if not d.pre_out else (1 if d.pre_out_kind == 2 else szc)                  # kind 2: DEMO_D8 codes, one byte per element
+        sz_pre = 0 if not d.act_grad_pre else {_lib.F32: 4, _lib.BF16: 2, _lib.D8: 1}[d.dtPre]
+        nbytes = nb * (2 * d.M * d.K + 2 * d.N * d.K + d.M * d.N * (szc + sz_pre_out)
                        + (d.M * d.N * (2 if d.dtRes == _lib.BF16 else 4) if d.residual else 0) + (d.M * d.N * 4 if d.accumulate else 0)
-                       + (d.M * d.N * (4 if d.dtPre == _lib.F32 else 2) if d.act_grad_pre else 0))
-        epi = "+".join(t for t, on in (("bias", d.bias), ("act", d.act), ("save_pre", d.pre_out), ("bf16_residual" if d.dtRes == _lib.BF16 else "fp32_residual", d.residual),
-                                       ("act_grad", d.act_grad_pre), ("accumulate", d.accumulate)) if on) or "plain"
+                       + d.M * d.N * sz_pre)
+        epi = "+".join(t for t, on in (("bias", d.bias), ("act", d.act), ("save_pre", d.pre_out and d.pre_out_kind == 0), ("save_deriv", d.pre_out and d.pre_out_kind == 1),
+                                       ("save_deriv_d8", d.pre_out and d.pre_out_kind == 2),
+                                       ("bf16_residual" if d.dtRes == _lib.BF16 else "fp32_residual", d.residual),
+                                       ("act_grad_d8" if d.dtPre == _lib.D8 else "act_grad", d.act_grad_pre), ("accumulate", d.accumulate)) if on) or "plain"
         recs[path].append((e0, e1, 2.0 * d.M * d.N * d.K * nb, nbytes, (d.M, d.N, d.K, epi)))
         return rc
 

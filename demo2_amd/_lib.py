@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("DEMO_HIP_LIB") or os.path.join(_HERE, "lib", "libdemo
 HEADER_PATH = os.path.join(_HERE, "..", "include", "demo_hip.h")
 
 F32, BF16 = 0, 1
+D8 = 2                # demo_hip.h DEMO_D8: 8-bit code of a saved activation derivative (uint8 tensors; demo_gemm's pre_out / act_grad_pre only)
 ERR_CAM_RANGE, ERR_LABEL_RANGE = 1, 2          # include/demo_hip.h: bits of the device error word
 ACT_NONE, ACT_QUICKGELU, ACT_GELU, ACT_SAVED = 0, 1, 2, 3      # ACT_SAVED: only as act_grad_kind (the operand is the derivative)
 

@@ -30,7 +30,9 @@ extern "C" int demo_gemm(const demo_gemm_desc* dp, void* stream) {
   DEMO_REQUIRE((d.dtA == DEMO_F32 || d.dtA == DEMO_BF16) && (d.dtB == DEMO_F32 || d.dtB == DEMO_BF16) &&
                    (d.dtC == DEMO_F32 || d.dtC == DEMO_BF16), "demo_gemm: bad dtype");
   DEMO_REQUIRE(!(d.accumulate && d.dtC != DEMO_F32), "demo_gemm: accumulate needs fp32 C");
-  hipStream_t s = (hipStream_t)stream;
+  DEMO_REQUIRE(!d.pre_out || (d.pre_out_kind >= 0 && d.pre_out_kind <= 2), "demo_gemm: pre_out_kind %d (0, 1 or 2)", d.pre_out_kind);
+  DEMO_REQUIRE(!d.act_grad_pre || d.dtPre == DEMO_F32 || d.dtPre == DEMO_BF16 || (d.dtPre == DEMO_D8 && d.act_grad_kind == DEMO_ACT_SAVED),
+               "demo_gemm: dtPre %d with act_grad_kind %d (DEMO_D8 holds a saved derivative: DEMO_ACT_SAVED only)", d.dtPre, d.act_grad_kind);  hipStream_t s = (hipStream_t)stream;
   if (demo_gemm_bf16_eligible(d)) return demo_gemm_bf16(d, s);
   return demo_gemm_generic(d, s);
 }

@@ -142,6 +142,24 @@ __device__ __forceinline__ float act_both(float x, int act, float& d) {
   return x;
 }
 
+// ---- DEMO_D8: 8-bit code of a saved activation derivative (demo_hip.h) ----------------------------------------------------------
+// q = rint((a + 0.13) * 200): the rounding is done explicitly (v_rndne_f32), so the byte conversion sees an integer and its own
+// rounding mode does not matter; v_cvt_pk_u8_f32 saturates to [0, 255] and inserts the byte into a dword.
+__device__ __forceinline__ uint32_t d8_pack4(float a0, float a1, float a2, float a3) {
+  uint32_t w = 0;
+  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(a0, 200.0f, 26.0f)), 0, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(a1, 200.0f, 26.0f)), 1, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(a2, 200.0f, 26.0f)), 2, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(a3, 200.0f, 26.0f)), 3, w);
+  return w;
+}
+__device__ __forceinline__ uint8_t d8_encode(float a) { return (uint8_t)(d8_pack4(a, 0.f, 0.f, 0.f) & 0xffu); }
+__device__ __forceinline__ float d8_decode(uint32_t q) { return fmaf((float)q, 0.005f, -0.13f); }
+// the four bytes of a dword (v_cvt_f32_ubyte0..3 + one fma each)
+__device__ __forceinline__ float4 d8_unpack4(uint32_t w) {
+  return make_float4(d8_decode(w & 0xffu), d8_decode((w >> 8) & 0xffu), d8_decode((w >> 16) & 0xffu), d8_decode(w >> 24));
+}
+
 // ---- attention kernels: 16-B output rows ----------------------------------------------------------------------------------------
 // Output rows: an accumulator tile gives a lane 4 consecutive d (8 B of bf16) of its key / query row, 16 rows x 32 B per store
 // instruction.  v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of another: applied to the packed

@@ -30,7 +30,7 @@ struct FArgs {
   const void* residual;        // fp32 (dtRes 0) or bf16 (dtRes DEMO_BF16), indexed like C
   const void* pre;
   void* pre_out;
-  int pre_out_kind;            // 0: pre-activation, 1: act'(pre-activation)
+  int pre_out_kind;            // 0: pre-activation, 1: act'(pre-activation), 2: act'(pre-activation) as DEMO_D8 codes (pre_out is a byte buffer)
   int dtRes;
   int M, N, K;
   int64_t lda, ldb, ldc;
@@ -103,20 +103,22 @@ __device__ __forceinline__ void epi4(const FArgs& p, const float4 b4, int64_t co
   const int64_t ci = coff + (int64_t)m * p.ldc + n;
   if (p.pre_out) {
     float s[4] = {v[0], v[1], v[2], v[3]};
-    if (p.pre_out_kind == 1) {
+    if (p.pre_out_kind >= 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = act_both(v[e], p.act, s[e]);
     }
-    if (p.dtC == DEMO_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.pre_out) + ci) = make_float4(s[0], s[1], s[2], s[3]);
+    if (p.pre_out_kind == 2) *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(p.pre_out) + ci) = d8_pack4(s[0], s[1], s[2], s[3]);
+    else if (p.dtC == DEMO_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.pre_out) + ci) = make_float4(s[0], s[1], s[2], s[3]);
     else io<bf16_t>::st4(reinterpret_cast<bf16_t*>(p.pre_out) + ci, make_float4(s[0], s[1], s[2], s[3]));
   }
-  if (p.act != DEMO_ACT_NONE && !(p.pre_out && p.pre_out_kind == 1)) {
+  if (p.act != DEMO_ACT_NONE && !(p.pre_out && p.pre_out_kind >= 1)) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act);
   }
   if (p.pre) {
     float4 pr;
-    if (p.dtPre == DEMO_BF16) pr = io<bf16_t>::ld4(reinterpret_cast<const bf16_t*>(p.pre) + ci);
+    if (p.dtPre == DEMO_D8) pr = d8_unpack4(*reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(p.pre) + ci));
+    else if (p.dtPre == DEMO_BF16) pr = io<bf16_t>::ld4(reinterpret_cast<const bf16_t*>(p.pre) + ci);
     else pr = io<float>::ld4(reinterpret_cast<const float*>(p.pre) + ci);
     v[0] *= act_grad(pr.x, p.act_grad_kind); v[1] *= act_grad(pr.y, p.act_grad_kind);
     v[2] *= act_grad(pr.z, p.act_grad_kind); v[3] *= act_grad(pr.w, p.act_grad_kind);
@@ -200,6 +202,16 @@ __device__ __forceinline__ void st16(void* base, int64_t off, const u32x4 v) {
   *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(base) + off) = v;
 #endif
 }
+// 8-B store of eight DEMO_D8 codes (the second output of an fc1 forward that saves act'(x) in 8 bits); off: BYTE offset
+__device__ __forceinline__ void st8(void* base, int64_t off, const uint2 v) {
+#if DEMO_EPI_ABLATE == 1
+  asm volatile("" ::"v"(v.x), "v"(v.y), "v"(off));
+#else
+  *reinterpret_cast<uint2*>(reinterpret_cast<char*>(base) + off) = v;
+#endif
+}
+__device__ __forceinline__ uint2 d8_pack8(const float (&s)[8]) { return make_uint2(d8_pack4(s[0], s[1], s[2], s[3]), d8_pack4(s[4], s[5], s[6], s[7])); }
+__device__ __forceinline__ void d8_unpack8(const uint2 r, float4& lo, float4& hi) { lo = d8_unpack4(r.x); hi = d8_unpack4(r.y); }
 __device__ __forceinline__ u32x4 as_u32x4(const uint4 r) { return (u32x4){r.x, r.y, r.z, r.w}; }
 __device__ __forceinline__ u32x4 as_u32x4(float a, float b, float c, float d) {
   return (u32x4){__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
@@ -213,7 +225,7 @@ __device__ __forceinline__ void epi8_compute(const FArgs& p, const float4 bz0, c
   const bool has_pre = GK >= 0 ? GK != DEMO_ACT_NONE : p.pre != nullptr;
   v[0] += bz0.x; v[1] += bz0.y; v[2] += bz0.z; v[3] += bz0.w;
   v[4] += bz1.x; v[5] += bz1.y; v[6] += bz1.z; v[7] += bz1.w;
-  const bool save_deriv = p.pre_out && p.pre_out_kind == 1;
+  const bool save_deriv = p.pre_out && p.pre_out_kind >= 1;
   if (p.pre_out) {
     if (save_deriv) {                                      // activation and its derivative from one exp / rcp (or erf) per element
 #pragma unroll
@@ -246,7 +258,9 @@ __device__ __forceinline__ void epi8_finish(const FArgs& p, const float4 bz0, co
   float s[8];
   epi8_compute<ACT, GK>(p, bz0, bz1, x, v, s);
   if (p.pre_out) {
-    if (p.dtC == DEMO_F32) {
+    if (p.pre_out_kind == 2) {
+      st8(p.pre_out, ci, d8_pack8(s));
+    } else if (p.dtC == DEMO_F32) {
       st16(p.pre_out, ci * 4, as_u32x4(s[0], s[1], s[2], s[3]));
       st16(p.pre_out, ci * 4 + 16, as_u32x4(s[4], s[5], s[6], s[7]));
     } else {
@@ -307,6 +321,12 @@ __device__ __forceinline__ void epi_rows_k(const FArgs& p, const float* __restri
         for (int u = 0; u < G; ++u) raw[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.pre) + ci[u]);
 #pragma unroll
         for (int u = 0; u < G; ++u) bf16x8_to_f32(raw[u], x[u].pre0, x[u].pre1);
+      } else if (p.dtPre == DEMO_D8) {
+        uint2 raw8[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) raw8[u] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(p.pre) + ci[u]);
+#pragma unroll
+        for (int u = 0; u < G; ++u) d8_unpack8(raw8[u], x[u].pre0, x[u].pre1);
       } else {
 #pragma unroll
         for (int u = 0; u < G; ++u) {
@@ -376,12 +396,31 @@ __device__ __forceinline__ void epi_rows(const FArgs& p, const float* __restrict
 // a store instruction cover 64 contiguous bytes of a row.  Rows are finished G row tiles at a time, every global operand of the
 // group requested first.
 // LOADS: which global operands besides the bias the epilogue reads, as a compile-time mask (1 fp32 residual, 5 = 1 | 4 bf16 residual, 2 act'(pre) source in bf16,
-// 0 none) or -1 = decided at run time (any combination, G = 1: every unit then budgets all 24 operand registers).
+// 10 = 2 | 8 saved derivative as DEMO_D8 codes, 0 none) or -1 = decided at run time (any combination, G = 1: every unit then budgets all 24 operand registers).
 // SINK 1 (bf16 outputs only): the finished values do not leave in the accumulator layout (16 rows x 64 B per store instruction: a
 // CU's store path moves ~10 B/clk that way, tools/probes/store_probe.hip) but through an LDS image of the output tile -- 256 rows x
 // 512 B over the main loop's ring, 16-B chunk index XOR (row & 31) -- from which every wave drains 32 whole rows, two per store
 // instruction (~20 B/clk per CU).  SINK 2 (two outputs: fc1 forward) works the tile in two 128-row halves, each with a 64-KB image per output.
+// SINK 3: the same with the second output as DEMO_D8 codes -- its half image is 128 rows x 256 B (8 B per lane and 8-column chunk; the 16-B
+// slot index XOR (row & 15) keeps both the 8-B writes and the 16-B drain reads on distinct banks), drained four whole rows per instruction.
 __device__ __forceinline__ unsigned pp_tile_slot(int row, int chunk) { return (unsigned)(row * 512 + ((chunk ^ (row & 31)) << 4)); }
+__device__ __forceinline__ unsigned pp_d8_slot(int row, int chunk) { return (unsigned)(row * 256 + ((((chunk >> 1) ^ row) & 15) << 4) + ((chunk & 1) << 3)); }
+__device__ __forceinline__ void pp_drain_half_d8(const FArgs& p, void* out, const char* img, int m0, int n0, int64_t coff, int half, int wave,
+                                                 int lane) {
+  u32x4 r[4];
+  const int rsub = lane >> 4, s16 = lane & 15;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int hr = wave * 16 + it * 4 + rsub;
+    r[it] = *reinterpret_cast<const u32x4*>(img + hr * 256 + (((s16 ^ hr) & 15) << 4));
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int hr = wave * 16 + it * 4 + rsub;
+    const int m = m0 + (hr >> 6) * 128 + half * 64 + (hr & 63);
+    if (m < p.M) st16(out, coff + (int64_t)m * p.ldc + n0 + s16 * 16, r[it]);        // (byte offsets: one byte per element)
+  }
+}
 __device__ __forceinline__ void pp_drain(const FArgs& p, void* out, const char* lds, int m0, int n0, int64_t coff, int wave, int lane) {
   u32x4 r[16];
   const int rsub = lane >> 5, chunk = lane & 31;
@@ -413,7 +452,8 @@ __device__ __forceinline__ void pp_epi_k(const FArgs& p, const f32x4 (&acc)[8][4
   const bool has_pre = LOADS >= 0 ? (LOADS & 2) != 0 : (GK >= 0 ? GK != DEMO_ACT_NONE : p.pre != nullptr);
   const bool has_res = LOADS >= 0 ? (LOADS & 1) != 0 : p.residual != nullptr;
   const bool has_old = LOADS >= 0 ? false : (p.accumulate && p.dtC == DEMO_F32);
-  const bool pre_bf16 = LOADS >= 0 ? true : p.dtPre == DEMO_BF16;
+  const bool pre_d8 = LOADS >= 0 ? (LOADS & 8) != 0 : p.dtPre == DEMO_D8;
+  const bool pre_bf16 = LOADS >= 0 ? !pre_d8 : p.dtPre == DEMO_BF16;
   const bool res_bf16 = LOADS >= 0 ? (LOADS & 4) != 0 : p.dtRes == DEMO_BF16;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 bz[2][2] = {{z4, z4}, {z4, z4}};
@@ -441,7 +481,17 @@ __device__ __forceinline__ void pp_epi_k(const FArgs& p, const f32x4 (&acc)[8][4
       }
     }
     if (has_pre) {
-      if (pre_bf16) {
+      if (pre_d8) {
+        uint2 raw8[G][2];
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) raw8[u][h] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(p.pre) + ci[u][h]);
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) d8_unpack8(raw8[u][h], x[u][h].pre0, x[u][h].pre1);
+      } else if (pre_bf16) {
         uint4 raw[G][2];
 #pragma unroll
         for (int u = 0; u < G; ++u)
@@ -501,9 +551,25 @@ __device__ __forceinline__ void pp_epi_k(const FArgs& p, const f32x4 (&acc)[8][4
         if constexpr (SINK == 0) {
           epi8_finish<ACT, GK>(p, bz[h][0], bz[h][1], x[u][h], ci[u][h], v);
         } else {
+          const int ch = ((ncol - n0) >> 3) + h * 4;
+          if constexpr (SINK == 3) {                   // activation + DEMO_D8 code of its derivative, each code packed as soon as it exists
+            static_assert(ACT > 0 && LOADS == 0, "SINK 3 is the fc1 forward: bias, activation, two outputs");
+            const float bb[8] = {bz[h][0].x, bz[h][0].y, bz[h][0].z, bz[h][0].w, bz[h][1].x, bz[h][1].y, bz[h][1].z, bz[h][1].w};
+            uint32_t w[2] = {0u, 0u};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float dv;
+              v[e] = act_both(v[e] + bb[e], ACT, dv);
+              w[e >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(dv, 200.0f, 26.0f)), e & 3, w[e >> 2]);
+              if (e == 3) __builtin_amdgcn_sched_barrier(0);     // four elements' transcendental temporaries at a time: the kernel sits at 256 VGPRs
+            }
+            const int hr = (mrow - m0) - ((mrow - m0) >> 7) * 64 + ((i0 + u) & 3) * 16;
+            *reinterpret_cast<uint2*>(lds + 65536 + pp_d8_slot(hr, ch)) = make_uint2(w[0], w[1]);
+            *reinterpret_cast<u32x4*>(lds + pp_tile_slot(hr, ch)) = as_u32x4(f32x8_to_bf16(v));
+            continue;
+          }
           float sv[8];
           epi8_compute<ACT, GK>(p, bz[h][0], bz[h][1], x[u][h], v, sv);
-          const int ch = ((ncol - n0) >> 3) + h * 4;
           if constexpr (SINK == 1) {
             *reinterpret_cast<u32x4*>(lds + pp_tile_slot(mrow - m0 + (i0 + u) * 16, ch)) = as_u32x4(f32x8_to_bf16(v));
           } else {                                   // two 128-row half images (C, second output): image row = wr * 64 + (i & 3) * 16 + frow
@@ -514,12 +580,13 @@ __device__ __forceinline__ void pp_epi_k(const FArgs& p, const f32x4 (&acc)[8][4
         }
       }
     }
-    if constexpr (SINK == 2) {                       // (G = 1) the wave's row tiles 0..3, then 4..7: drain both half images
+    if constexpr (SINK == 2 || SINK == 3) {          // (G = 1) the wave's row tiles 0..3, then 4..7: drain both half images
       if (i0 + G == 4 || i0 + G == 8) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         __syncthreads();
         pp_drain_half(p, p.C, lds, m0, n0, coff, (i0 + G) / 4 - 1, wave, lane);
-        pp_drain_half(p, p.pre_out, lds + 65536, m0, n0, coff, (i0 + G) / 4 - 1, wave, lane);
+        if constexpr (SINK == 2) pp_drain_half(p, p.pre_out, lds + 65536, m0, n0, coff, (i0 + G) / 4 - 1, wave, lane);
+        else pp_drain_half_d8(p, p.pre_out, lds + 65536, m0, n0, coff, (i0 + G) / 4 - 1, wave, lane);
         if (i0 + G == 4) __syncthreads();
       }
     }
@@ -530,43 +597,65 @@ __device__ __forceinline__ void pp_epi_k(const FArgs& p, const f32x4 (&acc)[8][4
     pp_drain(p, p.C, lds, m0, n0, coff, wave, lane);
   }
 }
+// FAM: the kernel is instantiated once per epilogue FAMILY so that neither instance carries (and allocates registers for) the other's
+// variants -- the kernel sits at 256 VGPRs, and the DEMO_D8 variants added to a single instance pushed two per-lane constants into scratch:
+//   0: descriptors WITHOUT a second output and WITHOUT an act' operand (bias / activation / residual / accumulate: qkv, proj, fc2, dX products)
+//   1: the MLP's special epilogues -- pre_out (fc1 forward saving the pre-activation, act', or its DEMO_D8 codes) or act_grad_pre (dY W2^T * act')
+template <int FAM>
 __device__ __forceinline__ void pp_epi(const FArgs& p, const f32x4 (&acc)[8][4], int mrow, int ncol, int64_t coff, const float* bias,
                                        char* lds = nullptr, int m0 = 0, int n0 = 0) {
   const int gk = p.pre ? p.act_grad_kind : DEMO_ACT_NONE;
   const bool old = p.accumulate && p.dtC == DEMO_F32;
-  if (lds && p.epi_stage && p.dtC == DEMO_BF16) {                   // whole-row stores through an LDS image of the tile (bf16 outputs)
-    if (!p.pre && !p.residual) {
-      if (p.pre_out) {                                       // fc1 forward: two outputs (pre-activation or act')
-        if (p.act == DEMO_ACT_QUICKGELU) { pp_epi_k<1, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE, 0, 2>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
-        if (p.act == DEMO_ACT_GELU) { pp_epi_k<1, DEMO_ACT_GELU, DEMO_ACT_NONE, 0, 2>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
-      } else {
-        if (p.act == DEMO_ACT_NONE) { pp_epi_k<1, DEMO_ACT_NONE, DEMO_ACT_NONE, 0, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
-        if (p.act == DEMO_ACT_QUICKGELU) { pp_epi_k<1, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE, 0, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
-      }
-    } else if (p.residual && p.dtRes == DEMO_BF16 && !p.pre && !p.pre_out && p.act == DEMO_ACT_NONE) {
+  const bool image = lds && p.epi_stage && p.dtC == DEMO_BF16;      // whole-row stores through an LDS image of the tile (bf16 outputs)
+  if constexpr (FAM == 0) {
+    if (image && !p.residual) {
+      if (p.act == DEMO_ACT_NONE) { pp_epi_k<1, DEMO_ACT_NONE, DEMO_ACT_NONE, 0, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
+      if (p.act == DEMO_ACT_QUICKGELU) { pp_epi_k<1, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE, 0, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
+    } else if (image && p.dtRes == DEMO_BF16 && p.act == DEMO_ACT_NONE) {
       pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_NONE, 5, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0);
       return;
-    } else if (p.pre && p.dtPre == DEMO_BF16 && !p.residual && !p.pre_out && p.act == DEMO_ACT_NONE) {
-      if (gk == DEMO_ACT_SAVED) { pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_SAVED, 2, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
-      if (gk == DEMO_ACT_QUICKGELU) { pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_QUICKGELU, 2, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
     }
-  }
-  if (!p.pre && !p.residual && !old) {                       // nothing to read but the bias: trunk qkv / fc1 forward, plain dX products
-    if (p.act == DEMO_ACT_NONE) pp_epi_k<1, DEMO_ACT_NONE, DEMO_ACT_NONE, 0>(p, acc, mrow, ncol, coff, bias);
-    else if (p.act == DEMO_ACT_QUICKGELU) pp_epi_k<1, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE, 0>(p, acc, mrow, ncol, coff, bias);
-    else if (p.act == DEMO_ACT_GELU) pp_epi_k<1, DEMO_ACT_GELU, DEMO_ACT_NONE, 0>(p, acc, mrow, ncol, coff, bias);
-    else pp_epi_k<1, -1, -1, -1>(p, acc, mrow, ncol, coff, bias);
-  } else if (p.residual && !p.pre && !old && p.act == DEMO_ACT_NONE) {       // proj / fc2 forward: + residual (fp32, or the bf16 stream)
-    if (p.dtRes == DEMO_BF16) pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_NONE, 5>(p, acc, mrow, ncol, coff, bias);
-    else pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_NONE, 1>(p, acc, mrow, ncol, coff, bias);
-  } else if (p.pre && p.dtPre == DEMO_BF16 && !p.residual && !old && p.act == DEMO_ACT_NONE && gk == DEMO_ACT_QUICKGELU) {
-    pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_QUICKGELU, 2>(p, acc, mrow, ncol, coff, bias);   // MLP backward: (dY W2^T) * act'(pre)
-  } else if (p.pre && p.dtPre == DEMO_BF16 && !p.residual && !old && p.act == DEMO_ACT_NONE && gk == DEMO_ACT_GELU) {
-    pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_GELU, 2>(p, acc, mrow, ncol, coff, bias);
-  } else if (p.pre && p.dtPre == DEMO_BF16 && !p.residual && !old && p.act == DEMO_ACT_NONE && gk == DEMO_ACT_SAVED) {
-    pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_SAVED, 2>(p, acc, mrow, ncol, coff, bias);       // MLP backward on a saved derivative: one multiply
+    if (!p.residual && !old) {                                 // nothing to read but the bias: trunk qkv forward, plain dX products
+      if (p.act == DEMO_ACT_NONE) pp_epi_k<1, DEMO_ACT_NONE, DEMO_ACT_NONE, 0>(p, acc, mrow, ncol, coff, bias);
+      else if (p.act == DEMO_ACT_QUICKGELU) pp_epi_k<1, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE, 0>(p, acc, mrow, ncol, coff, bias);
+      else if (p.act == DEMO_ACT_GELU) pp_epi_k<1, DEMO_ACT_GELU, DEMO_ACT_NONE, 0>(p, acc, mrow, ncol, coff, bias);
+      else pp_epi_k<1, -1, -1, -1>(p, acc, mrow, ncol, coff, bias);
+    } else if (p.residual && !old && p.act == DEMO_ACT_NONE) {       // proj / fc2 forward: + residual (fp32, or the bf16 stream)
+      if (p.dtRes == DEMO_BF16) pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_NONE, 5>(p, acc, mrow, ncol, coff, bias);
+      else pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_NONE, 1>(p, acc, mrow, ncol, coff, bias);
+    } else {
+      pp_epi_k<1, -1, -1, -1>(p, acc, mrow, ncol, coff, bias);
+    }
   } else {
-    pp_epi_k<1, -1, -1, -1>(p, acc, mrow, ncol, coff, bias);
+    if (image && !p.residual) {
+      if (!p.pre && p.pre_out && p.pre_out_kind == 2) {        // fc1 forward: two outputs, the second as DEMO_D8 codes of act'
+        if (p.act == DEMO_ACT_QUICKGELU) { pp_epi_k<1, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE, 0, 3>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
+        if (p.act == DEMO_ACT_GELU) { pp_epi_k<1, DEMO_ACT_GELU, DEMO_ACT_NONE, 0, 3>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
+      } else if (!p.pre && p.pre_out) {                        // fc1 forward: two outputs (pre-activation or act')
+        if (p.act == DEMO_ACT_QUICKGELU) { pp_epi_k<1, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE, 0, 2>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
+        if (p.act == DEMO_ACT_GELU) { pp_epi_k<1, DEMO_ACT_GELU, DEMO_ACT_NONE, 0, 2>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
+      } else if (p.pre && !p.pre_out && p.act == DEMO_ACT_NONE) {
+        if (p.dtPre == DEMO_D8 && gk == DEMO_ACT_SAVED) { pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_SAVED, 10, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }   // MLP backward on an 8-bit saved derivative
+        if (p.dtPre == DEMO_BF16 && gk == DEMO_ACT_SAVED) { pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_SAVED, 2, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
+        if (p.dtPre == DEMO_BF16 && gk == DEMO_ACT_QUICKGELU) { pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_QUICKGELU, 2, 1>(p, acc, mrow, ncol, coff, bias, lds, m0, n0); return; }
+      }
+    }
+    const bool plain_pre = p.pre && !p.pre_out && !p.residual && !old && p.act == DEMO_ACT_NONE;
+    if (plain_pre && p.dtPre == DEMO_BF16 && gk == DEMO_ACT_QUICKGELU) {
+      pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_QUICKGELU, 2>(p, acc, mrow, ncol, coff, bias);   // MLP backward: (dY W2^T) * act'(pre)
+    } else if (plain_pre && p.dtPre == DEMO_BF16 && gk == DEMO_ACT_GELU) {
+      pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_GELU, 2>(p, acc, mrow, ncol, coff, bias);
+    } else if (plain_pre && p.dtPre == DEMO_BF16 && gk == DEMO_ACT_SAVED) {
+      pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_SAVED, 2>(p, acc, mrow, ncol, coff, bias);       // MLP backward on a saved derivative: one multiply
+    } else if (plain_pre && p.dtPre == DEMO_D8 && gk == DEMO_ACT_SAVED) {
+      pp_epi_k<4, DEMO_ACT_NONE, DEMO_ACT_SAVED, 10>(p, acc, mrow, ncol, coff, bias);
+    } else if (!p.pre && !p.residual && !old && p.act == DEMO_ACT_QUICKGELU) {             // fc1 forward without the image (epi_stage off, fp32 C)
+      pp_epi_k<1, DEMO_ACT_QUICKGELU, DEMO_ACT_NONE, 0>(p, acc, mrow, ncol, coff, bias);
+    } else if (!p.pre && !p.residual && !old && p.act == DEMO_ACT_GELU) {
+      pp_epi_k<1, DEMO_ACT_GELU, DEMO_ACT_NONE, 0>(p, acc, mrow, ncol, coff, bias);
+    } else {
+      pp_epi_k<1, -1, -1, -1>(p, acc, mrow, ncol, coff, bias);
+    }
   }
 }
 
@@ -838,7 +927,7 @@ void gemm_bf16_nt_kernel(const FArgs p) {
 //   P4: (b0 still in registers)  vmcnt(0) before the first barrier                      MFMA acc[4..7][0..1]
 // Hazards: tile t+1 is read (P1 of t+1) two barriers after every wave's own vmcnt(0); buffer (t+1)&1 is re-staged at P1/P2 of
 // tile t, four barriers after its last ds_read (P3 of tile t-1) was waited for by the later half.
-template <bool REG_EPI>
+template <bool REG_EPI, int FAM>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) {
   constexpr int BM = 256, BN = 256, NW = 8;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -906,11 +995,23 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
   const int foff1 = frow * 128 + ((4 + (lane >> 4)) ^ sw) * 16;
   const int nk = p.K / BK;
 
-  f32x4 acc[8][4];
+  // The bias is the accumulators' INITIAL VALUE (register epilogue, alpha == 1): requested before the first operand tile, its latency
+  // overlaps the prologue's loads, and the epilogue neither loads nor adds it.  Requested at the top of the epilogue (the earlier form) the
+  // latency -- an L2 round trip under load -- was paid once per output tile with nothing to hide it, 7 to 9 times per launch on the K = 768
+  // products.  The lane's accumulator acc[i][2h], acc[i][2h+1] holds columns ncol + 32h + 0..3 / 4..7 (pp_epi_k), the same for every row
+  // tile i.  -DDEMO_BIAS_INIT=0 restores the late request (A/B variant of the library).
+#ifndef DEMO_BIAS_INIT
+#define DEMO_BIAS_INIT 1
+#endif
+  const bool bias_in_acc = DEMO_BIAS_INIT && REG_EPI && p.bias != nullptr && p.alpha == 1.0f;
+  f32x4 binit[4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int j = 0; j < 4; ++j) binit[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (bias_in_acc) {
+    const float* bp = p.bias + z * p.sBias + n0 + wc * 64 + (lane >> 4) * 8;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) binit[j] = *reinterpret_cast<const f32x4*>(bp + (j >> 1) * 32 + (j & 1) * 4);
+  }
 
   // (De-phasing the first round of workgroups with s_sleep, so that CUs do not reach their store-heavy epilogues together,
   // was tried in round 1 -- 2/4/8 phase groups, 7..17 us apart -- and measured 2..6 % slower on the training step.  Round 2
@@ -928,6 +1029,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
   } else {
     wait_vmcnt<0>();
   }
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = binit[j];
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();      // this half runs one barrier behind from here on
 
@@ -1067,7 +1173,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-    pp_epi(p, acc, m0 + wr * 128 + frow, n0 + wc * 64 + g4 * 8, coff, bias, smem, m0, n0);
+    pp_epi<FAM>(p, acc, m0 + wr * 128 + frow, n0 + wc * 64 + g4 * 8, coff, bias_in_acc ? nullptr : bias, smem, m0, n0);
 #endif
     return;
   }
@@ -1216,7 +1322,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_twin_kernel(const FArgs p
   }
   const int64_t coff = z * p.sC;
   const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
-  pp_epi(p, acc, m0 + wr * 128 + frow, n0 + wc * 64 + g4 * 8, coff, bias);
+  if (p.pre || p.pre_out) pp_epi<1>(p, acc, m0 + wr * 128 + frow, n0 + wc * 64 + g4 * 8, coff, bias);
+  else pp_epi<0>(p, acc, m0 + wr * 128 + frow, n0 + wc * 64 + g4 * 8, coff, bias);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1237,7 +1344,7 @@ int demo_gemm_bf16_eligible(const demo_gemm_desc& d) {
   if (d.pre_out && !al16(d.pre_out)) return 0;
   if (d.accumulate && d.dtC != DEMO_F32) return 0;
   // the row-major epilogue moves 8 columns (16 B of bf16) per access
-  if ((d.dtC == DEMO_BF16 || (d.act_grad_pre && d.dtPre == DEMO_BF16)) && d.c_rs % 8) return 0;
+  if ((d.dtC == DEMO_BF16 || (d.act_grad_pre && d.dtPre != DEMO_F32) || (d.pre_out && d.pre_out_kind == 2)) && d.c_rs % 8) return 0;
   if (d.batch1 != 1) {
     if (d.batch2 != 1) return 0;               // single-level batching only
   }
@@ -1279,7 +1386,7 @@ int demo_gemm_bf16_config(const demo_gemm_desc& d) {
     cfg = 1282;
     // act'(pre) epilogue at N=3072, K=768: 128^2 344 us, 256^2 with the LDS-staged epilogue 382 us (its operand registers spill), 256^2
     // with the register epilogue 319 us
-    if (d.N % 256 == 0 && d.M >= 1024 && (!d.act_grad_pre || (g_pp_reg_epi && d.dtPre == DEMO_BF16))) {
+    if (d.N % 256 == 0 && d.M >= 1024 && (!d.act_grad_pre || (g_pp_reg_epi && d.dtPre != DEMO_F32))) {
       const double rounds = (double)cdiv64(d.M, 256) * (d.N / 256) * nb / 256.0;
       const double eff = rounds / (double)(int64_t)(rounds + 0.999999);
       // fill threshold of the last round: 0.85 was the measured crossover with the LDS-staged epilogue; with the register epilogue
@@ -1354,12 +1461,12 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
     demo_gemm_desc a = d, b = d;
     a.M = m1;
     b.M = d.M - m1;
-    const int64_t szC = d.dtC == DEMO_F32 ? 4 : 2, szP = d.dtPre == DEMO_F32 ? 4 : 2;
+    const int64_t szC = d.dtC == DEMO_F32 ? 4 : 2, szP = d.dtPre == DEMO_F32 ? 4 : d.dtPre == DEMO_D8 ? 1 : 2;
     b.A = (const char*)d.A + (int64_t)m1 * d.a_rs * 2;
     b.C = (char*)d.C + (int64_t)m1 * d.c_rs * szC;
     if (d.residual) b.residual = (const char*)d.residual + (int64_t)m1 * d.c_rs * (d.dtRes == DEMO_BF16 ? 2 : 4);
     if (d.act_grad_pre) b.act_grad_pre = (const char*)d.act_grad_pre + (int64_t)m1 * d.c_rs * szP;
-    if (d.pre_out) b.pre_out = (char*)d.pre_out + (int64_t)m1 * d.c_rs * szC;
+    if (d.pre_out) b.pre_out = (char*)d.pre_out + (int64_t)m1 * d.c_rs * (d.pre_out_kind == 2 ? 1 : szC);
     // The two parts touch disjoint rows.  Issued back to back on one stream, the remainder runs alone on about half the CUs (282 small
     // tiles at 2 per CU).  Opt-in experiment (demo_gemm_set_split_overlap): forked onto a side stream it is ready at the same moment as the
     // main part and the caller's stream joins both before anything else runs.
@@ -1433,10 +1540,12 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
           p.group_m = 32 / c < 1 ? 1 : (32 / c > 8 ? 8 : 32 / c);
           grid = 8u * (unsigned)(cdiv64(p.ntm, R) * c);
         }
-        if (g_pp_reg_epi)
-          hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<true>, dim3(grid, (unsigned)nb), dim3(512), 0, s, p);
+        if (g_pp_reg_epi && (d.pre_out || d.act_grad_pre))           // epilogue family 1: the MLP's second output / act' operand (see pp_epi)
+          hipLaunchKernelGGL((gemm_bf16_nt_pp_kernel<true, 1>), dim3(grid, (unsigned)nb), dim3(512), 0, s, p);
+        else if (g_pp_reg_epi)
+          hipLaunchKernelGGL((gemm_bf16_nt_pp_kernel<true, 0>), dim3(grid, (unsigned)nb), dim3(512), 0, s, p);
         else
-          hipLaunchKernelGGL(gemm_bf16_nt_pp_kernel<false>, dim3(grid, (unsigned)nb), dim3(512), 0, s, p);
+          hipLaunchKernelGGL((gemm_bf16_nt_pp_kernel<false, 0>), dim3(grid, (unsigned)nb), dim3(512), 0, s, p);
       }
       break;
     case 2576:                                       // 256 x 128 twin kernel (two workgroups per CU)

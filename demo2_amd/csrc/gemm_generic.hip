@@ -110,16 +110,18 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GArgs args) {
         continue;
       }
       if (bias) v += bias[gn];
-      if (d.pre_out && d.pre_out_kind == 1) {
+      if (d.pre_out && d.pre_out_kind >= 1) {
         float dv;
         v = act_both(v, d.act, dv);
-        io<TC>::st(reinterpret_cast<TC*>(d.pre_out) + coff + ci, dv);
+        if (d.pre_out_kind == 2) reinterpret_cast<uint8_t*>(d.pre_out)[coff + ci] = d8_encode(dv);      // DEMO_D8 code
+        else io<TC>::st(reinterpret_cast<TC*>(d.pre_out) + coff + ci, dv);
       } else {
         if (d.pre_out) io<TC>::st(reinterpret_cast<TC*>(d.pre_out) + coff + ci, v);
         v = act_apply(v, d.act);
       }
       if (d.act_grad_pre) {
-        const float pre = d.dtPre == DEMO_BF16 ? ldg<bf16_t>(d.act_grad_pre, coff + ci) : ldg<float>(d.act_grad_pre, coff + ci);
+        const float pre = d.dtPre == DEMO_D8 ? d8_decode(reinterpret_cast<const uint8_t*>(d.act_grad_pre)[coff + ci])
+                        : d.dtPre == DEMO_BF16 ? ldg<bf16_t>(d.act_grad_pre, coff + ci) : ldg<float>(d.act_grad_pre, coff + ci);
         v *= act_grad(pre, d.act_grad_kind);
       }
       if (has_res) v += d.dtRes == DEMO_BF16 ? ldg<bf16_t>(d.residual, coff + ci) : ldg<float>(d.residual, coff + ci);

@@ -102,7 +102,7 @@ def trunk_forward(m, imgs: List[Tensor], cam: Optional[Tensor], T: torch.dtype, 
         r3 = ops.layernorm_fwd(x1, P.f(k["ln2"] + ".weight"), P.f(k["ln2"] + ".bias"), g.ln_eps, T, save=sv)
         h2 = r3[0] if sv else r3
         if sv:
-            pre = torch.empty(Bn * L, 4 * W, device=dev, dtype=T)
+            pre = torch.empty(Bn * L, 4 * W, device=dev, dtype=torch.uint8 if (deriv and m.act_deriv_d8) else T)     # uint8: DEMO_D8 codes of act'
             u = ops.gemm(h2, P.w(k["fc1_w"], T), bias=P.f(k["fc1_b"]), act=act, pre_out=pre, pre_out_deriv=deriv)
         else:
             pre = None
@@ -156,7 +156,7 @@ def _trunk_blocks_bf16_residual(m, x32: Tensor, Bn: int, L: int, W: int, act: in
         r3 = ops.layernorm_add_fwd(x1, None, P.f(k["ln2"] + ".weight"), P.f(k["ln2"] + ".bias"), g.ln_eps, save=sv)
         h2 = r3[0] if sv else r3
         if sv:
-            pre = torch.empty(Bn * L, 4 * W, device=dev, dtype=T)
+            pre = torch.empty(Bn * L, 4 * W, device=dev, dtype=torch.uint8 if (deriv and m.act_deriv_d8) else T)     # uint8: DEMO_D8 codes of act'
             u = ops.gemm(h2, P.w(k["fc1_w"], T), bias=P.f(k["fc1_b"]), act=act, pre_out=pre, pre_out_deriv=deriv)
         else:
             pre = None
@@ -197,7 +197,7 @@ def _trunk_blocks_bf16_stream(m, x32: Tensor, Bn: int, L: int, W: int, act: int,
         r3 = ops.layernorm_add_fwd(x_in, t_attn, P.f(k["ln2"] + ".weight"), P.f(k["ln2"] + ".bias"), g.ln_eps, xsum_out=x1, save=sv)
         h2 = r3[0] if sv else r3
         if sv:
-            pre = torch.empty(Bn * L, 4 * W, device=dev, dtype=T)
+            pre = torch.empty(Bn * L, 4 * W, device=dev, dtype=torch.uint8 if (deriv and m.act_deriv_d8) else T)     # uint8: DEMO_D8 codes of act'
             u = ops.gemm(h2, P.w(k["fc1_w"], T), bias=P.f(k["fc1_b"]), act=act, pre_out=pre, pre_out_deriv=deriv)
         else:
             pre = None

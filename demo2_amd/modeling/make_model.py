@@ -187,6 +187,10 @@ class DeMo(_Holder):
         self.bf16_residual = os.environ.get("DEMO_BF16_RESIDUAL", "1") != "0"
         # bf16 mode: the trunk's fc1 saves act'(pre) (not pre) for the backward; DEMO_SAVE_ACT_DERIV=0 restores the saved pre-activation
         self.save_act_deriv = os.environ.get("DEMO_SAVE_ACT_DERIV", "1") != "0"
+        # ... and saves it as DEMO_D8 codes (include/demo_hip.h: one byte per element, q = rint((a + 0.13) * 200), |error| <= 0.0025 -- the size
+        # of bf16's own half-ulp on [0.5, 2)): the (tokens, 4W) tensor the MLP backward re-reads is 152 instead of 304 MB per block at
+        # B = 128.  DEMO_ACT_DERIV_D8=0 keeps the derivative in bf16
+        self.act_deriv_d8 = os.environ.get("DEMO_ACT_DERIV_D8", "1") != "0"
         self.geom = self._make_geometry(cfg)
         self._flatten()
 

@@ -10,7 +10,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_SAVED, BF16, F32, GemmDesc, check
+from ._lib import ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_SAVED, BF16, D8, F32, GemmDesc, check
 
 Tensor = torch.Tensor
 
@@ -114,20 +114,31 @@ def gemm_raw(A: Tensor, B: Tensor, Cout: Tensor, M: int, N: int, K: int, a_rs: i
     d.sBias1, d.sBias2 = sBias
     if act_grad_pre is not None:
         d.act_grad_pre = act_grad_pre.data_ptr() + c_off * act_grad_pre.element_size()
-        d.dtPre = dt_code(act_grad_pre.dtype)
+        if act_grad_pre.dtype == torch.uint8:             # DEMO_D8 codes of a derivative an earlier forward saved (pre_out_deriv, uint8 pre_out)
+            if act_grad_kind != ACT_SAVED:
+                raise TypeError("a uint8 act_grad_pre holds DEMO_D8 codes of a saved derivative: act_grad_kind must be ACT_SAVED")
+            d.dtPre = D8
+        else:
+            d.dtPre = dt_code(act_grad_pre.dtype)
         d.act_grad_kind = act_grad_kind
     else:
         d.act_grad_pre = None
         d.dtPre = 0
         d.act_grad_kind = 0
     d.accumulate = 1 if accumulate else 0
+    d.pre_out_kind = 0
     if pre_out is not None:
-        if pre_out.dtype != Cout.dtype:
-            raise TypeError("pre_out must have the dtype of C")
+        if pre_out.dtype == torch.uint8:                  # act'(x) as DEMO_D8 codes, one byte per element
+            if not pre_out_deriv:
+                raise TypeError("a uint8 pre_out receives the DEMO_D8 codes of act'(x): pass pre_out_deriv=True")
+            d.pre_out_kind = 2
+        elif pre_out.dtype != Cout.dtype:
+            raise TypeError("pre_out must have the dtype of C (or uint8 with pre_out_deriv: DEMO_D8 codes)")
+        else:
+            d.pre_out_kind = 1 if pre_out_deriv else 0
         d.pre_out = pre_out.data_ptr() + c_off * pre_out.element_size()
     else:
         d.pre_out = None
-    d.pre_out_kind = 1 if (pre_out is not None and pre_out_deriv) else 0
     check(_lib.load().demo_gemm(C.byref(d), _stream()), "demo_gemm")
     return Cout
 
@@ -135,10 +146,12 @@ def gemm_raw(A: Tensor, B: Tensor, Cout: Tensor, M: int, N: int, K: int, a_rs: i
 def gemm(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, out_dtype: Optional[torch.dtype] = None,
          bias: Optional[Tensor] = None, residual: Optional[Tensor] = None, act: int = ACT_NONE, alpha: float = 1.0,
          act_grad_pre: Optional[Tensor] = None, act_grad_kind: int = 0, accumulate: bool = False,
-         pre_out: Optional[Tensor] = None, pre_out_new: bool = False, pre_out_deriv: bool = False):
+         pre_out: Optional[Tensor] = None, pre_out_new: bool = False, pre_out_deriv: bool = False, pre_out_d8: bool = False):
     """out[M,N] = act(alpha * a[M,K] @ b[N,K]^T + bias) (* act'(pre)) (+ residual).  a, b may be any 2-D strided views.
     pre_out receives the pre-activation, or its activation DERIVATIVE with pre_out_deriv (then the backward product takes
-    act_grad_kind=ACT_SAVED: one multiply instead of re-evaluating act' from the pre-activation)."""
+    act_grad_kind=ACT_SAVED: one multiply instead of re-evaluating act' from the pre-activation).  A uint8 pre_out (pre_out_new with
+    pre_out_d8) receives the derivative as DEMO_D8 codes (demo_hip.h: one byte per element, |error| <= 0.0025); the backward product
+    takes that uint8 tensor as act_grad_pre."""
     assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1], (a.shape, b.shape)
     M, K = a.shape
     N = b.shape[0]
@@ -150,7 +163,7 @@ def gemm(a: Tensor, b: Tensor, *, out: Optional[Tensor] = None, out_dtype: Optio
     if act_grad_pre is not None:
         assert act_grad_pre.shape == (M, N) and act_grad_pre.stride() == out.stride()
     if pre_out_new:
-        pre_out = torch.empty_like(out)
+        pre_out = torch.empty_like(out, dtype=torch.uint8) if (pre_out_d8 and pre_out_deriv) else torch.empty_like(out)
     if pre_out is not None:
         assert pre_out.shape == (M, N) and pre_out.stride() == out.stride()
     gemm_raw(a, b, out, M, N, K, a.stride(0), a.stride(1), b.stride(0), b.stride(1), out.stride(0), bias=bias,

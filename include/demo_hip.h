@@ -11,7 +11,8 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless said otherwise; sizes are element counts;
  *   - `stream` is a hipStream_t passed as void*;
- *   - dtype codes: DEMO_F32 = 0, DEMO_BF16 = 1.  "T" below = the compute/activation dtype;
+ *   - dtype codes: DEMO_F32 = 0, DEMO_BF16 = 1 (DEMO_D8 = 2: the 8-bit code of a saved activation derivative, demo_gemm only).
+ *     "T" below = the compute/activation dtype;
  *   - return value 0 = launched; negative = argument/launch error, text via demo_last_error().
  */
 #ifndef DEMO_HIP_H
@@ -25,6 +26,12 @@ extern "C" {
 
 #define DEMO_F32 0
 #define DEMO_BF16 1
+/* 8-bit fixed-point code of a saved activation DERIVATIVE (demo_gemm: pre_out_kind 2 writes it, dtPre DEMO_D8 reads it): one byte per
+ * element, q = rint((a + 0.13) * 200), a = q * 0.005 - 0.13.  act'(x) lies in [-0.0996, 1.0996] for QuickGELU and in [-0.1290, 1.1290] for
+ * erf-GELU, so q is in [0, 252]; absolute error <= 0.0025 everywhere (bf16's half-ulp is 0.0020 on [0.5, 1) and 0.0039 on [1, 2)); the
+ * saturated values 0 and 1 are codes of their own (26, 226: decoded to fp32 rounding, 2e-9 and 1.0).  Halves the bytes of the tensor
+ * the MLP backward re-reads. */
+#define DEMO_D8 2
 
 #define DEMO_ACT_NONE 0
 #define DEMO_ACT_QUICKGELU 1 /* x*sigmoid(1.702x): modeling/clip/model.py:163-165, modeling/moe/AttnMOE.py:5-7 */
@@ -64,9 +71,11 @@ typedef struct demo_gemm_desc {
   int32_t accumulate;     /* 1: C += result (fp32 C only) */
   void* pre_out;          /* optional: value BEFORE `act` (after alpha, bias), indexed and typed like C; saved for backward */
   int32_t dtRes;          /* dtype of `residual`: DEMO_F32 (0, the default) or DEMO_BF16 -- the bf16 residual stream of the bf16 compute mode */
-  int32_t pre_out_kind;   /* what pre_out receives: 0 = that pre-activation x, 1 = act'(x).  With 1 the backward product's epilogue is one
-                             multiply (act_grad_kind DEMO_ACT_SAVED) instead of re-evaluating the derivative from x: the exponential and
-                             the reciprocal are computed once, in the forward, where sigmoid(1.702x) / erf are needed anyway */
+  int32_t pre_out_kind;   /* what pre_out receives: 0 = that pre-activation x, 1 = act'(x), 2 = act'(x) as DEMO_D8 codes (pre_out is then a
+                             uint8 buffer indexed like C, one byte per element).  With 1 / 2 the backward product's epilogue is one
+                             multiply (act_grad_kind DEMO_ACT_SAVED; dtPre = dtC resp. DEMO_D8) instead of re-evaluating the derivative
+                             from x: the exponential and the reciprocal are computed once, in the forward, where sigmoid(1.702x) / erf
+                             are needed anyway */
 } demo_gemm_desc;
 int demo_gemm(const demo_gemm_desc* d, void* stream);
 /* what demo_gemm would pick: 0 = generic fp32-FMA kernel, 1 = bf16 MFMA 128x128 kernel, 2 = bf16 MFMA 256x256 ping-pong kernel */

@@ -136,6 +136,60 @@ def test_gemm_bf16_256_kernel_epilogues(M, N, K, reg_epi, tile):
         lib.demo_gemm_set_pp_epilogue(1)
 
 
+@pytest.mark.parametrize("force,dt,stage", [(0, torch.float32, 1), (1282, torch.bfloat16, 1), (2566, torch.bfloat16, 1), (2566, torch.bfloat16, 0),
+                                            (2576, torch.bfloat16, 1), (2562, torch.bfloat16, 1)])
+@pytest.mark.parametrize("kind", [ACT_QUICKGELU, ACT_GELU])
+def test_gemm_saved_activation_derivative_d8(force, dt, stage, kind):
+    """pre_out_kind 2 / dtPre DEMO_D8 (demo_hip.h): the forward epilogue saves act'(x) as one byte per element, q = rint((a + 0.13) * 200);
+    the backward product decodes a = q * 0.005 - 0.13 and multiplies.  Checked on the generic kernel, the 128^2 kernel, the 256^2 kernel
+    (register epilogue with and without the LDS image of the tile, LDS-staged epilogue, 256 x 128 twin), ragged M included:
+    the codes against the exact derivative (|error| <= half a step), the activation output unchanged, the backward product EXACTLY
+    equal (to the output's rounding) to the plain product times the decoded tensor, and the code range of both activations (the
+    saturated derivatives 0 and 1 are codes 26 and 226)."""
+    from demo2_amd import _lib
+    from demo2_amd._lib import ACT_SAVED
+    lib = _lib.load()
+    M, N, K = (300, 256, 192) if force in (0, 1282) else (2 * 256 + 77, 512, 128)
+    lp = dt == torch.bfloat16
+    a, b, bias = rnd(M, K) * 2.0, rnd(N, K, seed=1, scale=K ** -0.5), rnd(N, seed=2)
+    a[:4] *= 40.0                                          # saturated rows: act' -> 0 or 1 exactly
+    if lp:
+        a, b = a.bfloat16(), b.bfloat16()
+    x = (a.float() @ b.float().t() + bias).requires_grad_(True)
+    y_ref = act_ref(x, kind)
+    y_ref.sum().backward()
+    lib.demo_gemm_force_tile(force)
+    lib.demo_gemm_set_epi_stage(stage)
+    lib.demo_gemm_set_pp_epilogue(0 if force == 2562 else 1)
+    try:
+        fc = 2566 if force == 2562 else force
+        lib.demo_gemm_force_tile(fc)
+        y, codes = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), act=kind, pre_out_new=True, pre_out_deriv=True, pre_out_d8=True)
+        assert codes.dtype == torch.uint8 and codes.shape == (M, N)
+        tol = 1e-2 if lp else 1e-5
+        torch.testing.assert_close(y.float().cpu(), y_ref.detach(), rtol=tol, atol=tol)
+        dec = codes.cpu().float() * 0.005 - 0.13
+        # half a code step, plus what the bf16 operands' rounding moves the pre-activation (fp32 accumulation order only in the fp32 case)
+        err = (dec - x.grad).abs().max().item()
+        assert err <= 0.0025 + (2e-3 if lp else 1e-5), err
+        assert int(codes.max()) <= 252 and int(codes.min()) >= 0
+        sat = x.detach().abs() > 30.0
+        assert sat.any() and (dec[sat] - (x.detach()[sat] > 0).float()).abs().max().item() < 1e-6       # codes 26 / 226: 0 and 1 to fp32 rounding
+        # the backward product on the codes == the product times the decoded tensor
+        dy, w2t = rnd(M, 64, seed=4), rnd(N, 64, seed=5, scale=0.125)
+        if lp:
+            dy, w2t = dy.bfloat16(), w2t.bfloat16()
+        g_saved = ops.gemm(dy.to(DEV), w2t.to(DEV), act_grad_pre=codes, act_grad_kind=ACT_SAVED)
+        ref = (dy.float() @ w2t.float().t()) * dec
+        torch.testing.assert_close(g_saved.float().cpu(), ref, rtol=tol, atol=tol)
+        with pytest.raises(TypeError):
+            ops.gemm(dy.to(DEV), w2t.to(DEV), act_grad_pre=codes, act_grad_kind=kind)          # codes are a derivative, not a pre-activation
+    finally:
+        lib.demo_gemm_force_tile(0)
+        lib.demo_gemm_set_epi_stage(1)
+        lib.demo_gemm_set_pp_epilogue(1)
+
+
 @pytest.mark.parametrize("force,dt", [(0, torch.float32), (1282, torch.bfloat16), (2566, torch.bfloat16)])
 @pytest.mark.parametrize("kind", [ACT_QUICKGELU, ACT_GELU])
 def test_gemm_saved_activation_derivative(force, dt, kind):

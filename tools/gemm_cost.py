@@ -48,16 +48,25 @@ b1, b2, b3 = rn(4 * W), rn(W), rn(3 * W)
 res32 = rn(M, W)
 o16 = torch.empty(M, 4 * W, device=dev, dtype=torch.bfloat16)
 p16 = (rn(M, 4 * W) * 0.5).bfloat16()
+p8 = torch.randint(0, 253, (M, 4 * W), device=dev, dtype=torch.uint8)
 o3 = torch.empty(M, 3 * W, device=dev, dtype=torch.bfloat16)
 o32 = torch.empty(M, W, device=dev)
 o16s = torch.empty(M, W, device=dev, dtype=torch.bfloat16)
 cases = [
     ("qkv fwd   bias                      N=2304 K=768 ", 2.0 * M * 3 * W * W, lambda: ops.gemm(x, wqkv, bias=b3, out=o3)),
+    ("qkv fwd   plain                     N=2304 K=768 ", 2.0 * M * 3 * W * W, lambda: ops.gemm(x, wqkv, out=o3)),
+    ("fc1 fwd   plain                     N=3072 K=768 ", 2.0 * M * 4 * W * W, lambda: ops.gemm(x, w1, out=o16)),
     ("fc1 fwd   bias+quickgelu+save act'  N=3072 K=768 ", 2.0 * M * 4 * W * W,
      lambda: ops.gemm(x, w1, bias=b1, out=o16, act=_lib.ACT_QUICKGELU, pre_out=p16, pre_out_deriv=True)),
+    ("fc1 fwd   bias+quickgelu+save act' D8 N=3072 K=768", 2.0 * M * 4 * W * W,
+     lambda: ops.gemm(x, w1, bias=b1, out=o16, act=_lib.ACT_QUICKGELU, pre_out=p8, pre_out_deriv=True)),
+    ("fc1 fwd   bias+quickgelu (1 output) N=3072 K=768 ", 2.0 * M * 4 * W * W,
+     lambda: ops.gemm(x, w1, bias=b1, out=o16, act=_lib.ACT_QUICKGELU)),
     ("fc1 fwd   bias only                 N=3072 K=768 ", 2.0 * M * 4 * W * W, lambda: ops.gemm(x, w1, bias=b1, out=o16)),
     ("fc2 bwd   * saved act'              N=3072 K=768 ", 2.0 * M * 4 * W * W,
      lambda: ops.gemm(x, w1, out=o16, act_grad_pre=p16, act_grad_kind=_lib.ACT_SAVED)),
+    ("fc2 bwd   * saved act' D8           N=3072 K=768 ", 2.0 * M * 4 * W * W,
+     lambda: ops.gemm(x, w1, out=o16, act_grad_pre=p8, act_grad_kind=_lib.ACT_SAVED)),
     ("fc2 fwd   bias+fp32 residual        N=768  K=3072", 2.0 * M * 4 * W * W, lambda: ops.gemm(h, w2, bias=b2, residual=res32, out=o32)),
     ("fc1 bwd   plain                     N=768  K=3072", 2.0 * M * 4 * W * W, lambda: ops.gemm(h, w2, out=o16s)),
     ("qkv bwd   plain                     N=768  K=2304", 2.0 * M * 3 * W * W, lambda: ops.gemm(q3, wqkvT, out=o16s)),
