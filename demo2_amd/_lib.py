@@ -54,6 +54,7 @@ PROTOTYPES = {
     "demo_gemm_set_pp_epilogue": [C.c_int],
     "demo_gemm_set_pp_min_fill": [C.c_int],
     "demo_gemm_set_dephase": [C.c_int],
+    "demo_gemm_generic_tile": [C.c_int],
     "demo_gemm_set_colslice": [C.c_int],
     "demo_gemm_set_epi_stage": [C.c_int],
     "demo_gemm_set_split_overlap": [C.c_int],
@@ -152,6 +153,8 @@ def load():
         lib.demo_gemm_set_pp_min_fill(int(os.environ["DEMO_PP_MIN_FILL"]))      # 85: the pre-register-epilogue kernel choice
     if "DEMO_ATTN_VARIANT" in os.environ:
         lib.demo_attention_set_variant(int(os.environ["DEMO_ATTN_VARIANT"]))    # 0: round-1 attention forward (Q, K, V in LDS)
+    if "DEMO_GENERIC_TILE" in os.environ:
+        lib.demo_gemm_generic_tile(int(os.environ["DEMO_GENERIC_TILE"]))        # generic fp32 kernel: 32 / 64 forced (0 = heuristic)
     if "DEMO_GEMM_DEPHASE" in os.environ:
         lib.demo_gemm_set_dephase(int(os.environ["DEMO_GEMM_DEPHASE"]))         # 256x256 kernel: start offsets of the first round
     if "DEMO_GEMM_SPLIT_OVERLAP" in os.environ:

@@ -438,6 +438,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_pp_kernel(const TArgs p) 
         for (int r = 0; r < 4; ++r) atomicAdd(p.colsum + m0 + wr * 128 + (ii * 4 + wc) * 16 + 4 * g + r, csum[ii][r]);
     }
   }
+  if (p.partial) {
+    // Two-pass split-K: the slice's partial tile goes to the workspace IN ACCUMULATOR ORDER -- one float4 per lane and MFMA tile, 1 KiB
+    // contiguous per wave instruction, [item][wave][i][j][lane] -- instead of the output's row-major order, where a register's four values
+    // are four rows x 64-byte runs (4-B stores, 1024 wave instructions per tile against 256 here).  Only tn_reduce_kernel reads the
+    // workspace; it works in the same order and scatters the ONE final image into C.
+    float4* dst = reinterpret_cast<float4*>(p.partial) + (int64_t)item * (PBM * PBN / 4) + wave * (32 * 64) + lane;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        dst[(i * 4 + j) * 64] = make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha);
+    return;
+  }
   // D[row = m_local = 4g + reg][col = n_local = lane & 15]: per register 4 rows x 64 contiguous bytes
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -448,10 +461,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_pp_kernel(const TArgs p) 
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wr * 128 + ((i & 4) + ((i + wc) & 3)) * 16 + 4 * g + r;      // rotated row-tile order
         const float v = acc[i][j][r] * p.alpha;
-        if (p.partial) {                                     // slice `split` of the partial-tile workspace, plain stores
-          p.partial[((int64_t)split * p.Mo + m) * p.No + n] = v;
-          continue;
-        }
         float* c = p.C + (int64_t)m * p.ldc + n;
         if (p.use_atomics) atomicAdd(c, v);
         else *c = p.accumulate ? *c + v : v;
@@ -460,27 +469,32 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_tn_pp_kernel(const TArgs p) 
   }
 }
 
-// second pass of the two-pass split-K form: C (+)= sum over slices of the partial tiles.  One float4 of C per thread.
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ partial, int splitk, int Mo, int No, float* __restrict__ C,
+// second pass of the two-pass split-K form: C (+)= sum over slices of the partial tiles.  The workspace holds every (slice, tile) item in
+// the first pass's accumulator order (see there); a thread owns one float4 of that order -- four consecutive output ROWS of one column,
+// lane-adjacent threads adjacent columns -- sums it over the slices with 16-B loads and scatters the four values into C.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ partial, int splitk, int ntm, int ntn, float* __restrict__ C,
                                                         int64_t ldc, int accumulate) {
-  const int64_t q = blockIdx.x * 256 + threadIdx.x;         // float4 index inside the (Mo, No) tile image
-  const int64_t total4 = (int64_t)Mo * No / 4;
-  if (q >= total4) return;
-  const int64_t slice4 = total4;
+  const int tiles = ntm * ntn;
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;          // float4 index: tile * 16384 + position inside the tile
+  if (q >= (int64_t)tiles * (PBM * PBN / 4)) return;
+  const int tile = (int)(q >> 14), e = (int)(q & 16383);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4* p4 = reinterpret_cast<const float4*>(partial) + q;
+  const int64_t slice4 = (int64_t)tiles * (PBM * PBN / 4);
 #pragma unroll 4
   for (int k = 0; k < splitk; ++k) {
     const float4 v = p4[k * slice4];
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
-  const int64_t e = q * 4, m = e / No, n = e - m * No;
-  float4* c = reinterpret_cast<float4*>(C + m * ldc + n);
-  if (accumulate) {
-    const float4 o = *c;
-    s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
-  }
-  *c = s;
+  const int wave = e >> 11, i = (e >> 8) & 7, j = (e >> 6) & 3, lane = e & 63;
+  const int wr = wave >> 2, wc = wave & 3, g = lane >> 4, idx = lane & 15;
+  const int tm = tile / ntn, tn = tile - tm * ntn;
+  const int m = tm * PBM + wr * 128 + ((i & 4) + ((i + wc) & 3)) * 16 + 4 * g;        // (rotated row-tile order of the first pass)
+  const int n = tn * PBN + wc * 64 + j * 16 + idx;
+  float* c = C + (int64_t)m * ldc + n;
+  const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r * ldc] = accumulate ? c[r * ldc] + v[r] : v[r];
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -545,7 +559,7 @@ extern "C" int demo_gemm_tn_bf16(const void* A, const void* B, float* C, int32_t
     else hipLaunchKernelGGL(gemm_bf16_tn_pp_kernel<false>, dim3(nwg), dim3(512), 0, s, p);
     DEMO_LAUNCH_CHECK("demo_gemm_tn_bf16(256)");
     if (two_pass) {
-      hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv64((int64_t)Mo * No / 4, 256)), dim3(256), 0, s, workspace, p.splitk, Mo, No, C,
+      hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv64((int64_t)Mo * No / 4, 256)), dim3(256), 0, s, workspace, p.splitk, p.ntm, p.ntn, C,
                          ldc, accumulate);
       DEMO_LAUNCH_CHECK("demo_gemm_tn_bf16(reduce)");
     }

@@ -6,8 +6,12 @@
 
 namespace {
 
-constexpr int GT = 64;   // output tile is GT x GT
 constexpr int GK = 32;   // k-step
+// The output tile is GT x GT, GT = 64 (16 x 16 threads, 4 x 4 outputs each) or 32 (2 x 2 outputs each).  The products this kernel serves on
+// the path are a few hundred rows at most (the batch, or 3 x the batch): a 64^2 grid is then a few dozen workgroups of ONE wave per SIMD
+// each, every K-step an unhidden chain {global loads -> LDS -> 512 dependent-issue FMAs} of ~1.3 us.  With 32^2 tiles the same product
+// is four times the workgroups -- more CUs busy, several waves per SIMD -- at a quarter of the FMAs per thread and step; it pays whenever
+// the 64^2 grid would not fill the chip (launch_c).
 
 template <typename T> __device__ __forceinline__ float ldg(const void* p, int64_t i) {
   return io<T>::ld(reinterpret_cast<const T*>(p) + i);
@@ -19,9 +23,10 @@ struct GArgs {
   int kper;     // reduction elements per slice (multiple of GK)
 };
 
-template <typename TA, typename TB, typename TC>
+template <typename TA, typename TB, typename TC, int GT>
 __global__ __launch_bounds__(256) void gemm_generic_kernel(const GArgs args) {
   const demo_gemm_desc& d = args.d;
+  constexpr int TT = GT / 16;          // outputs per thread and dimension
   __shared__ float As[GK][GT + 4];
   __shared__ float Bs[GK][GT + 4];
 
@@ -37,17 +42,17 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GArgs args) {
 
   const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
   const int t = threadIdx.x;
-  const int ty = t >> 4, tx = t & 15;   // 16 x 16 threads, 4x4 outputs each
+  const int ty = t >> 4, tx = t & 15;   // 16 x 16 threads, TT x TT outputs each
 
   // load mapping: walk the contiguous direction fastest
   const bool a_kfast = (d.a_cs == 1) || (d.a_rs != 1);
   const bool b_kfast = (d.b_cs == 1) || (d.b_rs != 1);
 
-  float acc[4][4];
+  float acc[TT][TT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int j = 0; j < TT; ++j) acc[i][j] = 0.f;
 
   // One K-step ahead in registers: the loads of step s+1 are issued before the FMAs of step s, so a step costs one memory
   // latency OR its arithmetic, not their sum (the skinny products here are a few workgroups walking a long K: the
@@ -59,10 +64,10 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GArgs args) {
     for (int i = 0; i < LPT; ++i) {
       const int idx = t + i * 256;
       int r, k;
-      if (a_kfast) { r = idx / GK; k = idx % GK; } else { r = idx & 63; k = idx >> 6; }
+      if (a_kfast) { r = idx / GK; k = idx % GK; } else { r = idx % GT; k = idx / GT; }
       const int gm = m0 + r, gk = k0 + k;
       ra[i] = (gm < d.M && gk < kend) ? io<TA>::ld(A + (int64_t)gm * d.a_rs + (int64_t)gk * d.a_cs) : 0.f;
-      if (b_kfast) { r = idx / GK; k = idx % GK; } else { r = idx & 63; k = idx >> 6; }
+      if (b_kfast) { r = idx / GK; k = idx % GK; } else { r = idx % GT; k = idx / GT; }
       const int gn = n0 + r, gk2 = k0 + k;
       rb[i] = (gn < d.N && gk2 < kend) ? io<TB>::ld(B + (int64_t)gn * d.b_rs + (int64_t)gk2 * d.b_cs) : 0.f;
     }
@@ -73,34 +78,42 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GArgs args) {
     for (int i = 0; i < LPT; ++i) {
       const int idx = t + i * 256;
       int r, k;
-      if (a_kfast) { r = idx / GK; k = idx % GK; } else { r = idx & 63; k = idx >> 6; }
+      if (a_kfast) { r = idx / GK; k = idx % GK; } else { r = idx % GT; k = idx / GT; }
       As[k][r] = ra[i];
-      if (b_kfast) { r = idx / GK; k = idx % GK; } else { r = idx & 63; k = idx >> 6; }
+      if (b_kfast) { r = idx / GK; k = idx % GK; } else { r = idx % GT; k = idx / GT; }
       Bs[k][r] = rb[i];
     }
     __syncthreads();
     if (k0 + GK < kend) fetch(k0 + GK);
 #pragma unroll
     for (int k = 0; k < GK; ++k) {
-      const float4 a = *reinterpret_cast<const float4*>(&As[k][ty * 4]);
-      const float4 b = *reinterpret_cast<const float4*>(&Bs[k][tx * 4]);
-      const float av[4] = {a.x, a.y, a.z, a.w};
-      const float bv[4] = {b.x, b.y, b.z, b.w};
+      float av[TT], bv[TT];
+      if constexpr (TT == 4) {
+        const float4 a = *reinterpret_cast<const float4*>(&As[k][ty * 4]);
+        const float4 b = *reinterpret_cast<const float4*>(&Bs[k][tx * 4]);
+        av[0] = a.x; av[1] = a.y; av[2] = a.z; av[3] = a.w;
+        bv[0] = b.x; bv[1] = b.y; bv[2] = b.z; bv[3] = b.w;
+      } else {
+        const float2 a = *reinterpret_cast<const float2*>(&As[k][ty * 2]);
+        const float2 b = *reinterpret_cast<const float2*>(&Bs[k][tx * 2]);
+        av[0] = a.x; av[1] = a.y;
+        bv[0] = b.x; bv[1] = b.y;
+      }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+        for (int j = 0; j < TT; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
     }
     __syncthreads();
   }
 
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int gm = m0 + ty * 4 + i;
+  for (int i = 0; i < TT; ++i) {
+    const int gm = m0 + ty * TT + i;
     if (gm >= d.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int gn = n0 + tx * 4 + j;
+    for (int j = 0; j < TT; ++j) {
+      const int gn = n0 + tx * TT + j;
       if (gn >= d.N) continue;
       float v = acc[i][j] * d.alpha;
       const int64_t ci = (int64_t)gm * d.c_rs + gn;
@@ -139,12 +152,15 @@ __global__ __launch_bounds__(256) void clear_c_kernel(float* __restrict__ C, int
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < mn; i += (int64_t)gridDim.x * 256) c[(i / N) * c_rs + (i % N)] = 0.f;
 }
 
+int g_generic_tile = 0;     // tuning / test hook (demo_gemm_generic_tile): 0 = heuristic, 32 / 64 = that tile for every generic launch
+
 template <typename TA, typename TB>
 int launch_c(const demo_gemm_desc& d, hipStream_t s) {
   GArgs a;
   a.d = d;
   a.splitk = 1;
   a.kper = d.K;
+  constexpr int GT = 64;
   const int64_t tiles = cdiv64(d.N, GT) * cdiv64(d.M, GT) * d.batch1 * d.batch2;
   // skinny products with a long reduction (classifier 128 x 171 x 3584, gate Linear 128 x 512 x 3584 ...): a handful of
   // workgroups would walk K serially at one memory latency per 16-deep step -> split the reduction across workgroups
@@ -173,16 +189,29 @@ int launch_c(const demo_gemm_desc& d, hipStream_t s) {
       }
     }
   }
+  // 32^2 tiles when the 64^2 grid (slices included) would leave most of the 256 CUs idle or at one wave per SIMD
+  const bool small = g_generic_tile == 32 || (g_generic_tile == 0 && tiles * a.splitk < 384);
+  if (small) {
+    dim3 grid((unsigned)cdiv64(d.N, 32), (unsigned)cdiv64(d.M, 32), (unsigned)(d.batch1 * d.batch2 * a.splitk));
+    if (d.dtC == DEMO_F32)
+      hipLaunchKernelGGL((gemm_generic_kernel<TA, TB, float, 32>), grid, dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((gemm_generic_kernel<TA, TB, bf16_t, 32>), grid, dim3(256), 0, s, a);
+    DEMO_LAUNCH_CHECK("demo_gemm(generic 32)");
+    return 0;
+  }
   dim3 grid((unsigned)cdiv64(d.N, GT), (unsigned)cdiv64(d.M, GT), (unsigned)(d.batch1 * d.batch2 * a.splitk));
   if (d.dtC == DEMO_F32)
-    hipLaunchKernelGGL((gemm_generic_kernel<TA, TB, float>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((gemm_generic_kernel<TA, TB, float, 64>), grid, dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((gemm_generic_kernel<TA, TB, bf16_t>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((gemm_generic_kernel<TA, TB, bf16_t, 64>), grid, dim3(256), 0, s, a);
   DEMO_LAUNCH_CHECK("demo_gemm(generic)");
   return 0;
 }
 
 }  // namespace
+
+extern "C" int demo_gemm_generic_tile(int t) { g_generic_tile = (t == 32 || t == 64) ? t : 0; return 0; }
 
 int demo_gemm_generic(const demo_gemm_desc& d, hipStream_t s) {
   if (d.dtA == DEMO_F32 && d.dtB == DEMO_F32) return launch_c<float, float>(d, s);

@@ -94,6 +94,7 @@ int demo_gemm_set_colslice(int s);   /* tuning hook, 256x256 kernel: 2 / 4 / 8 =
 int demo_gemm_set_dephase(int units); /* tuning hook, 256x256 kernel: first-round workgroups start ((id >> 3) & 3) * units * 64 clocks late (default 0) */
 int demo_gemm_store_policy(void); /* cache policy the MFMA NT kernels' output stores were BUILT with (-DDEMO_STORE_POL): 0 default, 1 nt, 2 sc1 (write-through) */
 int demo_gemm_desc_size(void); /* sizeof(demo_gemm_desc): lets a foreign binding verify its struct layout */
+int demo_gemm_generic_tile(int tile); /* tuning / test hook, generic fp32-FMA kernel: 32 / 64 = that output tile for every launch, 0 = heuristic (32 x 32 tiles when the 64 x 64 grid would not fill the chip) */
 
 /* ---- elementwise / layout ----------------------------------------------------------------- */
 /* fp32 -> bf16 shadow copy of the flat parameter buffer (one launch per optimizer step). */

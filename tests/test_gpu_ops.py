@@ -29,13 +29,27 @@ def act_ref(x, act):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("tile", [0, 32, 64])
 @pytest.mark.parametrize("M,N,K", [(37, 171, 100), (1, 512, 64), (129, 64, 17), (300, 256, 192)])
 @pytest.mark.parametrize("act", [ACT_NONE, ACT_QUICKGELU, ACT_GELU])
-def test_gemm_generic_fp32(M, N, K, act):
+def test_gemm_generic_fp32(M, N, K, act, tile):
+    """tile: the generic kernel's output tile (demo_gemm_generic_tile: 32 / 64 forced, 0 = the dispatcher's choice)."""
+    from demo2_amd import _lib
+    lib = _lib.load()
     a, b, bias, res = rnd(M, K), rnd(N, K, seed=1), rnd(N, seed=2), rnd(M, N, seed=3)
     want = act_ref(0.5 * a @ b.t() + bias, act) + res
-    got = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), residual=res.to(DEV), act=act, alpha=0.5)
+    lib.demo_gemm_generic_tile(tile)
+    try:
+        got = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), residual=res.to(DEV), act=act, alpha=0.5)
+        # a transposed (column-major) B view and a split-K shape (long reduction, few tiles) through the same tile
+        got_t = ops.gemm(a.to(DEV), b.t().contiguous().to(DEV).t(), bias=bias.to(DEV), residual=res.to(DEV), act=act, alpha=0.5)
+        a2, b2 = rnd(64, 1536, seed=5), rnd(96, 1536, seed=6, scale=1536 ** -0.5)
+        got_sk = ops.gemm(a2.to(DEV), b2.to(DEV))
+    finally:
+        lib.demo_gemm_generic_tile(0)
     torch.testing.assert_close(got.cpu(), want, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(got_t.cpu(), want, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(got_sk.cpu(), a2 @ b2.t(), rtol=1e-4, atol=1e-4)
 
 
 def test_gemm_generic_strides_batches_and_epilogues():

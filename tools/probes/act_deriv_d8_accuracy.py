@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Gradient accuracy of the bf16 compute mode with the saved activation derivative kept in bf16 or as DEMO_D8 codes (one byte per element,
+model.act_deriv_d8 / DEMO_ACT_DERIV_D8), config A at full size (12 blocks), B = 8, against the same model's own fp32 compute mode
+(dropout off).  Prints, over all parameters with a non-negligible gradient, the norm-relative error: median / 90th / max, the error of the
+whole flat gradient, and the distance between the two bf16 variants themselves."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+from demo2_amd.modeling import make_model  # noqa: E402
+from demo2_amd.modeling.hip_backward import TrainStep  # noqa: E402
+from util import make_cfg, synth_batch  # noqa: E402
+
+cfg = make_cfg("RGBNT201")
+torch.manual_seed(0)
+m = make_model(cfg, 171, 4, 0)
+with torch.no_grad():                                     # the module's own initialisation, made "alive": biases, BN statistics, token scale
+    g_ = torch.Generator().manual_seed(1)
+    for n_, p_ in m.named_parameters():
+        p_.add_(torch.randn(p_.shape, generator=g_) * (0.02 if p_.dim() > 1 else 0.05))
+    for n_, b_ in m.named_buffers():
+        if "running_var" in n_:
+            b_.mul_(1 + 0.1 * torch.rand(b_.shape, generator=g_))
+        elif "running_mean" in n_:
+            b_.add_(0.1 * torch.randn(b_.shape, generator=g_))
+m = m.to("cuda").train()
+m.geom.hdm_dropout = 0.0
+x, cam = synth_batch(8, 256, 128, 4, device="cuda")
+target = torch.tensor([3, 3, 3, 3, 9, 9, 9, 9], device="cuda")
+grads = {}
+VARIANTS = (("fp32", torch.float32, False), ("bf16, act' in bf16", torch.bfloat16, False), ("bf16, act' as D8 codes", torch.bfloat16, True))
+m.train()
+stats0 = m.stab.flat.clone()
+for name, dt, d8 in VARIANTS:
+    m.set_compute_dtype(dt)
+    m.act_deriv_d8 = d8
+    m.stab.flat.copy_(stats0)
+    ts = TrainStep(m, cfg, 1, optimizer=False)
+    m.grad_buffer().zero_()
+    loss = ts.step(x, target, cam)
+    torch.cuda.synchronize()
+    grads[name] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.requires_grad}
+    print(f"{name:24s} loss {loss.item():.5f}")
+
+
+def compare(a, b, label):
+    errs, num, den = [], 0.0, 0.0
+    for n, g in grads[a].items():
+        r = grads[b][n]
+        if r.norm() > 1e-6:
+            errs.append(((g - r).norm() / r.norm()).item())
+        num += (g - r).double().pow(2).sum().item()
+        den += r.double().pow(2).sum().item()
+    e = torch.tensor(errs)
+    print(f"{label:44s} per-parameter relative error: median {e.median():.4f}  p90 {e.quantile(0.9):.4f}  max {e.max():.4f}   whole gradient {(num / den) ** 0.5:.4f}")
+
+
+compare("bf16, act' in bf16", "fp32", "bf16 (act' in bf16)      vs fp32 mode")
+compare("bf16, act' as D8 codes", "fp32", "bf16 (act' as D8 codes)  vs fp32 mode")
+compare("bf16, act' as D8 codes", "bf16, act' in bf16", "D8 codes vs bf16 derivative (both bf16 mode)")
