@@ -6,16 +6,9 @@
 
 namespace {
 
-constexpr int GK = 32;   // k-step
-// The output tile is GT x GT, GT = 64 (16 x 16 threads, 4 x 4 outputs each) or 32 (2 x 2 outputs each).  The products this kernel serves on
-// the path are a few hundred rows at most (the batch, or 3 x the batch): a 64^2 grid is then a few dozen workgroups of ONE wave per SIMD
-// each, every K-step an unhidden chain {global loads -> LDS -> 512 dependent-issue FMAs} of ~1.3 us.  With 32^2 tiles the same product
-// is four times the workgroups -- more CUs busy, several waves per SIMD -- at a quarter of the FMAs per thread and step; it pays whenever
-// the 64^2 grid would not fill the chip (launch_c).
-
-template <typename T> __device__ __forceinline__ float ldg(const void* p, int64_t i) {
-  return io<T>::ld(reinterpret_cast<const T*>(p) + i);
-}
+// GK: reduction elements per step (32 for both tile forms; 64- and 128-deep steps of the 32^2 form -- fewer, fatter {global load -> LDS ->
+// barrier} chains, 16 loads per thread and operand in flight -- measured equal and slower on the training step: registers and LDS per
+// workgroup cost the co-resident workgroups that hide the chain).
 
 struct GArgs {
   demo_gemm_desc d;
@@ -23,7 +16,7 @@ struct GArgs {
   int kper;     // reduction elements per slice (multiple of GK)
 };
 
-template <typename TA, typename TB, typename TC, int GT>
+template <typename TA, typename TB, typename TC, int GT, int GK>
 __global__ __launch_bounds__(256) void gemm_generic_kernel(const GArgs args) {
   const demo_gemm_desc& d = args.d;
   constexpr int TT = GT / 16;          // outputs per thread and dimension
@@ -152,6 +145,9 @@ __global__ __launch_bounds__(256) void clear_c_kernel(float* __restrict__ C, int
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < mn; i += (int64_t)gridDim.x * 256) c[(i / N) * c_rs + (i % N)] = 0.f;
 }
 
+#ifndef DEMO_GENERIC_GK32
+#define DEMO_GENERIC_GK32 32      // reduction elements per step of the 32^2 form (A/B on the training step: 32 and 64 equal, 128 slower)
+#endif
 int g_generic_tile = 0;     // tuning / test hook (demo_gemm_generic_tile): 0 = heuristic, 32 / 64 = that tile for every generic launch
 
 template <typename TA, typename TB>
@@ -160,23 +156,26 @@ int launch_c(const demo_gemm_desc& d, hipStream_t s) {
   a.d = d;
   a.splitk = 1;
   a.kper = d.K;
-  constexpr int GT = 64;
-  const int64_t tiles = cdiv64(d.N, GT) * cdiv64(d.M, GT) * d.batch1 * d.batch2;
+  const int nb = d.batch1 * d.batch2;
+  const int64_t tiles64 = cdiv64(d.N, 64) * cdiv64(d.M, 64) * nb;
+  // 32^2 tiles (128-deep steps) when the 64^2 grid would leave most of the 256 CUs idle or at one wave per SIMD
+  const bool small = g_generic_tile == 32 || (g_generic_tile == 0 && tiles64 < 384);
+  const int GT = small ? 32 : 64, GKs = small ? DEMO_GENERIC_GK32 : 32;
+  const int64_t tiles = cdiv64(d.N, GT) * cdiv64(d.M, GT) * nb;
   // skinny products with a long reduction (classifier 128 x 171 x 3584, gate Linear 128 x 512 x 3584 ...): a handful of
-  // workgroups would walk K serially at one memory latency per 16-deep step -> split the reduction across workgroups
+  // workgroups would walk K serially at one memory latency per step -> split the reduction across workgroups
   const bool linear_epi = d.act == DEMO_ACT_NONE && !d.pre_out && !d.act_grad_pre && !d.residual && d.dtC == DEMO_F32;
-  if (linear_epi && tiles < 128 && d.K >= 512) {
-    int sk = (int)(256 / tiles);
-    const int maxk = d.K / 128;
+  if (linear_epi && tiles64 < 128 && d.K >= 512) {
+    int sk = (int)((small ? 1024 : 256) / tiles);
+    const int maxk = d.K / 128;                           // at least 128 reduction elements per slice
     if (sk > maxk) sk = maxk;
     if (sk > 64) sk = 64;
     if (sk > 1) {
-      const int ksteps = (int)cdiv64(d.K, GK);
+      const int ksteps = (int)cdiv64(d.K, GKs);
       const int per = (int)cdiv64(ksteps, sk);
-      a.kper = per * GK;
+      a.kper = per * GKs;
       a.splitk = (int)cdiv64(ksteps, per);
-      if (!d.accumulate) {                                       // slices add into C: clear it first (rows may be strided)
-        const int nb = d.batch1 * d.batch2;
+      if (a.splitk > 1 && !d.accumulate) {                       // slices add into C: clear it first (rows may be strided)
         if (nb == 1) {
           hipError_t e = hipMemset2DAsync(d.C, (size_t)d.c_rs * sizeof(float), 0, (size_t)d.N * sizeof(float), (size_t)d.M, s);
           if (e != hipSuccess) DEMO_FAIL(-2, "demo_gemm(generic): memset failed: %s", hipGetErrorString(e));
@@ -189,22 +188,18 @@ int launch_c(const demo_gemm_desc& d, hipStream_t s) {
       }
     }
   }
-  // 32^2 tiles when the 64^2 grid (slices included) would leave most of the 256 CUs idle or at one wave per SIMD
-  const bool small = g_generic_tile == 32 || (g_generic_tile == 0 && tiles * a.splitk < 384);
+  dim3 grid((unsigned)cdiv64(d.N, GT), (unsigned)cdiv64(d.M, GT), (unsigned)(nb * a.splitk));
   if (small) {
-    dim3 grid((unsigned)cdiv64(d.N, 32), (unsigned)cdiv64(d.M, 32), (unsigned)(d.batch1 * d.batch2 * a.splitk));
     if (d.dtC == DEMO_F32)
-      hipLaunchKernelGGL((gemm_generic_kernel<TA, TB, float, 32>), grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((gemm_generic_kernel<TA, TB, float, 32, DEMO_GENERIC_GK32>), grid, dim3(256), 0, s, a);
     else
-      hipLaunchKernelGGL((gemm_generic_kernel<TA, TB, bf16_t, 32>), grid, dim3(256), 0, s, a);
-    DEMO_LAUNCH_CHECK("demo_gemm(generic 32)");
-    return 0;
+      hipLaunchKernelGGL((gemm_generic_kernel<TA, TB, bf16_t, 32, DEMO_GENERIC_GK32>), grid, dim3(256), 0, s, a);
+  } else {
+    if (d.dtC == DEMO_F32)
+      hipLaunchKernelGGL((gemm_generic_kernel<TA, TB, float, 64, 32>), grid, dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((gemm_generic_kernel<TA, TB, bf16_t, 64, 32>), grid, dim3(256), 0, s, a);
   }
-  dim3 grid((unsigned)cdiv64(d.N, GT), (unsigned)cdiv64(d.M, GT), (unsigned)(d.batch1 * d.batch2 * a.splitk));
-  if (d.dtC == DEMO_F32)
-    hipLaunchKernelGGL((gemm_generic_kernel<TA, TB, float, 64>), grid, dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL((gemm_generic_kernel<TA, TB, bf16_t, 64>), grid, dim3(256), 0, s, a);
   DEMO_LAUNCH_CHECK("demo_gemm(generic)");
   return 0;
 }
