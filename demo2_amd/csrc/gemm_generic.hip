@@ -10,6 +10,10 @@ namespace {
 // barrier} chains, 16 loads per thread and operand in flight -- measured equal and slower on the training step: registers and LDS per
 // workgroup cost the co-resident workgroups that hide the chain).
 
+template <typename T> __device__ __forceinline__ float ldg(const void* p, int64_t i) {
+  return io<T>::ld(reinterpret_cast<const T*>(p) + i);
+}
+
 struct GArgs {
   demo_gemm_desc d;
   int splitk;   // > 1: blockIdx.z = batch * splitk + slice; slices combine with fp32 atomics (C pre-zeroed or accumulated into)
