@@ -6,6 +6,11 @@
 
 namespace {
 
+// The output tile is GT x GT, GT = 64 (16 x 16 threads, 4 x 4 outputs each) or 32 (2 x 2 outputs each).  The products this kernel serves on
+// the path are a few hundred rows at most (the batch, or 3 x the batch): a 64^2 grid is then a few dozen workgroups of ONE wave per SIMD
+// each, every K-step an unhidden chain {global loads -> LDS -> 512 dependent-issue FMAs} of ~1.3 us.  With 32^2 tiles the same product
+// is four times the workgroups -- more CUs busy, several waves per SIMD -- at a quarter of the FMAs per thread and step; it is taken
+// whenever the 64^2 grid would not fill the chip (launch_c).  Same-box A/B of the training step: 35.17 -> 34.90 ms.
 // GK: reduction elements per step (32 for both tile forms; 64- and 128-deep steps of the 32^2 form -- fewer, fatter {global load -> LDS ->
 // barrier} chains, 16 loads per thread and operand in flight -- measured equal and slower on the training step: registers and LDS per
 // workgroup cost the co-resident workgroups that hide the chain).
