@@ -478,8 +478,14 @@ def test_small_layout_kernels():
     xb = x.bfloat16().reshape(-1)
     assert torch.equal(ops.cast_bf16_f32(xb.to(DEV), torch.empty(7000, device=DEV)).cpu(), xb.float())
     for dt in (torch.float32, torch.bfloat16):
-        t = rnd(130, 70).to(dt)
-        assert torch.equal(ops.transpose(t.to(DEV)).cpu(), t.t().contiguous())
+        for shape in ((130, 70), (136, 72), (768, 2304), (200, 64)):      # multiples of 8 take the 16-B-access bf16 form, ragged tiles included
+            t = rnd(*shape).to(dt)
+            assert torch.equal(ops.transpose(t.to(DEV)).cpu(), t.t().contiguous())
+    flat = rnd(3 * 5000).bfloat16().to(DEV)                                  # batched form on equally spaced matrices of a flat buffer
+    dstb = torch.empty(3, 48, 72, device=DEV, dtype=torch.bfloat16)
+    ops.transpose_batched(flat, 8, 5000, 72, 48, 3, dstb)
+    for z in range(3):
+        assert torch.equal(dstb[z].cpu(), flat[8 + z * 5000: 8 + z * 5000 + 72 * 48].view(72, 48).t().contiguous().cpu())
     t = rnd(777, 100)
     torch.testing.assert_close(ops.colsum(t.to(DEV)).cpu(), t.sum(0), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(ops.colsum(t.bfloat16().to(DEV)).cpu(), t.bfloat16().float().sum(0), rtol=1e-4, atol=1e-3)
