@@ -99,27 +99,29 @@ def gemm_roofline(model, step_fn):
             path = lib.demo_gemm_path(C.byref(d))
             if path not in recs:
                 return orig(dref, stream)
-            m1 = lib.demo_gemm_split_rows(C.byref(d))
-            if m1 <= 0:
+            rows, cfgs = (C.c_int32 * 4)(), (C.c_int32 * 4)()
+            nparts = lib.demo_gemm_split_plan(C.byref(d), rows, cfgs, 4)
+            if nparts <= 1:
                 return timed(d, path)
-            # demo_gemm issues this descriptor as two launches (rows [0, m1) on the 256^2 kernel, the rest on the 128^2
-            # kernel): issue the same two launches from here so that each kernel gets its own event pair
-            d1, d2 = _lib.GemmDesc.from_buffer_copy(d), _lib.GemmDesc.from_buffer_copy(d)
-            d1.M, d2.M = m1, d.M - m1
-            szc, szp = (4 if d.dtC == _lib.F32 else 2), (4 if d.dtPre == _lib.F32 else 2)
-            d2.A = d.A + m1 * d.a_rs * 2
-            d2.C = d.C + m1 * d.c_rs * szc
-            if d.residual:
-                d2.residual = d.residual + m1 * d.c_rs * (2 if d.dtRes == _lib.BF16 else 4)
-            if d.act_grad_pre:
-                d2.act_grad_pre = d.act_grad_pre + m1 * d.c_rs * szp
-            if d.pre_out:
-                d2.pre_out = d.pre_out + m1 * d.c_rs * szc
+            # demo_gemm issues this descriptor as several launches over disjoint row ranges (main + remainder on the 128^2 kernel, or
+            # equal parts on the 256^2 kernel): issue the same launches from here so that each one gets its own event pair
+            szc, szp = (4 if d.dtC == _lib.F32 else 2), {_lib.F32: 4, _lib.BF16: 2, _lib.D8: 1}[d.dtPre] if d.act_grad_pre else 0
+            rc, m0 = 0, 0
             try:
-                lib.demo_gemm_force_tile(2566)
-                rc = timed(d1, 2)
-                lib.demo_gemm_force_tile(1282)
-                rc = rc or timed(d2, 1)
+                for i in range(nparts):
+                    di = _lib.GemmDesc.from_buffer_copy(d)
+                    di.M = rows[i]
+                    di.A = d.A + m0 * d.a_rs * 2
+                    di.C = d.C + m0 * d.c_rs * szc
+                    if d.residual:
+                        di.residual = d.residual + m0 * d.c_rs * (2 if d.dtRes == _lib.BF16 else 4)
+                    if d.act_grad_pre:
+                        di.act_grad_pre = d.act_grad_pre + m0 * d.c_rs * szp
+                    if d.pre_out:
+                        di.pre_out = d.pre_out + m0 * d.c_rs * (1 if d.pre_out_kind == 2 else szc)
+                    m0 += rows[i]
+                    lib.demo_gemm_force_tile(cfgs[i])
+                    rc = rc or timed(di, 2 if cfgs[i] == 2566 else 1)
             finally:
                 lib.demo_gemm_force_tile(0)
             return rc

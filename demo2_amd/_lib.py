@@ -50,6 +50,8 @@ PROTOTYPES = {
     "demo_gemm_force_tile": [C.c_int],
     "demo_gemm_path": [C.POINTER(GemmDesc)],
     "demo_gemm_split_rows": [C.POINTER(GemmDesc)],
+    "demo_gemm_split_plan": [C.POINTER(GemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32],
+    "demo_gemm_set_split_equal": [C.c_int],
     "demo_gemm_set_split": [C.c_int],
     "demo_gemm_set_pp_epilogue": [C.c_int],
     "demo_gemm_set_pp_min_fill": [C.c_int],
@@ -153,6 +155,8 @@ def load():
         lib.demo_gemm_set_pp_min_fill(int(os.environ["DEMO_PP_MIN_FILL"]))      # 85: the pre-register-epilogue kernel choice
     if "DEMO_ATTN_VARIANT" in os.environ:
         lib.demo_attention_set_variant(int(os.environ["DEMO_ATTN_VARIANT"]))    # 0: round-1 attention forward (Q, K, V in LDS)
+    if "DEMO_GEMM_SPLIT_EQUAL" in os.environ:
+        lib.demo_gemm_set_split_equal(int(os.environ["DEMO_GEMM_SPLIT_EQUAL"]))   # partial-round products as equal 256^2 launches up to this K (0 = never)
     if "DEMO_GENERIC_TILE" in os.environ:
         lib.demo_gemm_generic_tile(int(os.environ["DEMO_GENERIC_TILE"]))        # generic fp32 kernel: 32 / 64 forced (0 = heuristic)
     if "DEMO_GEMM_DEPHASE" in os.environ:

@@ -19,6 +19,12 @@ extern "C" int demo_gemm_split_rows(const demo_gemm_desc* d) {
   if (!d || !demo_gemm_bf16_eligible(*d)) return 0;
   return demo_gemm_bf16_split_rows(*d);
 }
+int demo_gemm_bf16_split_plan(const demo_gemm_desc& d, int32_t* rows, int32_t* cfg, int max_parts);
+extern "C" int demo_gemm_split_plan(const demo_gemm_desc* d, int32_t* rows, int32_t* cfg, int32_t max_parts) {
+  if (!d || !rows || !cfg || max_parts < 1) return 0;
+  if (!demo_gemm_bf16_eligible(*d)) { rows[0] = d->M; cfg[0] = 0; return 1; }
+  return demo_gemm_bf16_split_plan(*d, rows, cfg, max_parts);
+}
 extern "C" int demo_gemm_desc_size(void) { return (int)sizeof(demo_gemm_desc); }
 
 extern "C" int demo_gemm(const demo_gemm_desc* dp, void* stream) {

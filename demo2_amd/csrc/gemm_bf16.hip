@@ -1414,21 +1414,57 @@ int demo_gemm_bf16_config(const demo_gemm_desc& d) {
 }
 
 // Row split of a 256^2 launch whose tile count leaves a small last round (582 tiles on 256 CUs = 2.27 rounds at N = 768,
-// M = 49536: a third round running 27 % full): the rows that fill whole rounds go to the 256^2 kernel, the rest to the 128^2
-// kernel, whose 4x smaller tiles at 2 workgroups/CU cover them in one short round.  Returns the rows of the first part
-// (a multiple of 256), 0 = no split.  g_split_left: largest leftover (in 256^2 tiles) that is split off; 0 disables.
+// M = 49536: a third round running 27 % full).  Two plans:
+//   (a) main + remainder: the rows that fill whole rounds go to the 256^2 kernel, the rest to the 128^2 kernel, whose 4x smaller
+//       tiles at 2 workgroups/CU cover them in one short round (round 1);
+//   (b) EQUAL PARTS (round 3): full + 1 launches of the 256^2 kernel with ~tiles / (full + 1) tiles each, every CU at most one tile
+//       per launch -- no 128^2 launch (half the flops per byte fed to LDS) and no two-round lock-step.  Measured inside the training step,
+//       same box, interleaved runs: taken for the K = 768 products of N = 768 (attention output projection and its dX) 35.98 -> ~35.75 ms;
+//       taken for the long-K products as well (K = 2304 / 3072) 35.89, for the long-K products alone 36.14 -- there plan (a) stays.
+//       (An isolated microbenchmark, tools/bench_cu_fill.py, shows a 256^2 tile at 66 us with 195 tiles in flight against 78 us with 255
+//       at K = 3072 -- the L2 -> LDS feed is shared chip-wide -- and so predicted the opposite for long K; it re-reads ONE part's rows
+//       from a warm Infinity Cache, which the step's three parts do not.)  g_split_eq_max_k: largest K that takes plan (b); 0 = never,
+//       the default: 0.12 ms of 35.7 (three runs per arm) is inside the box-to-box spread, so the plan stays an opt-in hook
+//       (demo_gemm_set_split_equal(1024), DEMO_GEMM_SPLIT_EQUAL=1024).
+// demo_gemm_bf16_split_plan: rows[i] of each part (multiples of 256 but the last) and its kernel configuration; returns the number of
+// parts (1 = one launch).  g_split_left: largest leftover (in 256^2 tiles) that is split off; 0 disables both plans.
 extern "C" int demo_gemm_set_pp_epilogue(int reg) { g_pp_reg_epi = reg != 0; return 0; }
 static int g_split_left = 128;
+static int g_split_eq_max_k = 0;       // OFF by default: -0.12 ms of a 35.7 ms step at 1024, see above
 extern "C" int demo_gemm_set_split(int max_left_tiles) { g_split_left = max_left_tiles; return 0; }
-int demo_gemm_bf16_split_rows(const demo_gemm_desc& d) {
-  if (g_force_tile != 0 || g_split_left <= 0 || d.batch1 * d.batch2 != 1) return 0;
-  if (demo_gemm_bf16_config(d) != 2566) return 0;
+extern "C" int demo_gemm_set_split_equal(int max_k) { g_split_eq_max_k = max_k; return 0; }      // 0 = never (plan (a) only)
+int demo_gemm_bf16_split_plan(const demo_gemm_desc& d, int32_t* rows, int32_t* cfg, int max_parts) {
+  rows[0] = d.M;
+  cfg[0] = 0;
+  if (max_parts < 2 || g_force_tile != 0 || g_split_left <= 0 || d.batch1 * d.batch2 != 1) return 1;
+  if (demo_gemm_bf16_config(d) != 2566) return 1;
   const int64_t ntm = cdiv64(d.M, 256), ntn = d.N / 256, total = ntm * ntn;
   const int64_t full = total / 256, left = total - full * 256;
-  if (full < 1 || left < 32 || left > g_split_left) return 0;   // (a last round under ~1/8 full finishes fast enough on its own: fc1 forward, 24 tiles, measured)
+  if (full < 1 || left < 32 || left > g_split_left) return 1;   // (a last round under ~1/8 full finishes fast enough on its own: fc1 forward, 24 tiles, measured)
+  if (d.K <= g_split_eq_max_k && full + 1 <= max_parts && full <= 3) {
+    const int parts = (int)full + 1;
+    const int64_t per = cdiv64(ntm, parts);                     // row panels per part
+    if (per * ntn <= 256 && per * (parts - 1) < ntm) {
+      int64_t done = 0;
+      for (int i = 0; i < parts; ++i) {
+        const int64_t pm = i + 1 < parts ? per * 256 : d.M - done;
+        rows[i] = (int32_t)pm;
+        cfg[i] = 2566;
+        done += pm;
+      }
+      return parts;
+    }
+  }
   const int64_t tm1 = full * 256 / ntn;
-  if (tm1 < 1 || tm1 * 256 >= d.M) return 0;
-  return (int)(tm1 * 256);
+  if (tm1 < 1 || tm1 * 256 >= d.M) return 1;
+  rows[0] = (int32_t)(tm1 * 256); cfg[0] = 2566;
+  rows[1] = (int32_t)(d.M - tm1 * 256); cfg[1] = 1282;
+  return 2;
+}
+// (kept for callers of the round-1 ABI: rows of the first part when the product is split, 0 = one launch)
+int demo_gemm_bf16_split_rows(const demo_gemm_desc& d) {
+  int32_t rows[4], cfg[4];
+  return demo_gemm_bf16_split_plan(d, rows, cfg, 4) > 1 ? rows[0] : 0;
 }
 
 // Side stream of the row split (one per host thread and device: the library is entered from the caller's thread and from autograd's).
@@ -1466,31 +1502,36 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
 int demo_gemm_bf16(const demo_gemm_desc& d, hipStream_t s) { return demo_gemm_bf16_launch(d, s, 0); }
 
 static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg_override) {
-  const int m1 = cfg_override ? 0 : demo_gemm_bf16_split_rows(d);
-  if (m1 > 0) {
-    demo_gemm_desc a = d, b = d;
-    a.M = m1;
-    b.M = d.M - m1;
+  int32_t prow[4], pcfg[4];
+  const int nparts = cfg_override ? 1 : demo_gemm_bf16_split_plan(d, prow, pcfg, 4);
+  if (nparts > 1) {
     const int64_t szC = d.dtC == DEMO_F32 ? 4 : 2, szP = d.dtPre == DEMO_F32 ? 4 : d.dtPre == DEMO_D8 ? 1 : 2;
-    b.A = (const char*)d.A + (int64_t)m1 * d.a_rs * 2;
-    b.C = (char*)d.C + (int64_t)m1 * d.c_rs * szC;
-    if (d.residual) b.residual = (const char*)d.residual + (int64_t)m1 * d.c_rs * (d.dtRes == DEMO_BF16 ? 2 : 4);
-    if (d.act_grad_pre) b.act_grad_pre = (const char*)d.act_grad_pre + (int64_t)m1 * d.c_rs * szP;
-    if (d.pre_out) b.pre_out = (char*)d.pre_out + (int64_t)m1 * d.c_rs * (d.pre_out_kind == 2 ? 1 : szC);
-    // The two parts touch disjoint rows.  Issued back to back on one stream, the remainder runs alone on about half the CUs (282 small
-    // tiles at 2 per CU).  Opt-in experiment (demo_gemm_set_split_overlap): forked onto a side stream it is ready at the same moment as the
-    // main part and the caller's stream joins both before anything else runs.
-    SideStream* side = g_split_overlap ? side_stream() : nullptr;
+    demo_gemm_desc part[4];
+    int64_t m0 = 0;
+    for (int i = 0; i < nparts; ++i) {                    // the parts touch disjoint rows
+      demo_gemm_desc& b = part[i];
+      b = d;
+      b.M = prow[i];
+      b.A = (const char*)d.A + m0 * d.a_rs * 2;
+      b.C = (char*)d.C + m0 * d.c_rs * szC;
+      if (d.residual) b.residual = (const char*)d.residual + m0 * d.c_rs * (d.dtRes == DEMO_BF16 ? 2 : 4);
+      if (d.act_grad_pre) b.act_grad_pre = (const char*)d.act_grad_pre + m0 * d.c_rs * szP;
+      if (d.pre_out) b.pre_out = (char*)d.pre_out + m0 * d.c_rs * (d.pre_out_kind == 2 ? 1 : szC);
+      m0 += prow[i];
+    }
+    // Issued back to back on the caller's stream.  Opt-in experiment for plan (a) (demo_gemm_set_split_overlap): the remainder forked onto
+    // a side stream, ready at the same moment as the main part; the caller's stream joins both before anything else runs.
+    SideStream* side = (g_split_overlap && nparts == 2 && pcfg[1] == 1282) ? side_stream() : nullptr;
     if (side && hipEventRecord(side->fork, s) == hipSuccess && hipStreamWaitEvent(side->st, side->fork, 0) == hipSuccess) {
-      int rc = demo_gemm_bf16_launch(b, side->st, 1282);
+      int rc = demo_gemm_bf16_launch(part[1], side->st, 1282);
       const hipError_t e1 = hipEventRecord(side->join, side->st);
-      if (rc == 0) rc = demo_gemm_bf16_launch(a, s, 2566);
+      if (rc == 0) rc = demo_gemm_bf16_launch(part[0], s, 2566);
       const hipError_t e2 = hipStreamWaitEvent(s, side->join, 0);
       if (rc == 0 && (e1 != hipSuccess || e2 != hipSuccess)) DEMO_FAIL(-2, "demo_gemm: joining the side stream failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
       return rc;
     }
-    int rc = demo_gemm_bf16_launch(a, s, 2566);
-    if (rc == 0) rc = demo_gemm_bf16_launch(b, s, 1282);
+    int rc = 0;
+    for (int i = 0; i < nparts && rc == 0; ++i) rc = demo_gemm_bf16_launch(part[i], s, pcfg[i]);
     return rc;
   }
   FArgs p;

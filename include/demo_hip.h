@@ -85,6 +85,13 @@ int demo_gemm_force_tile(int tile); /* tuning hook: 128 / 256 forces that MFMA t
  * (whole rounds of the 256 CUs) and rows [r, M) on the 128x128 kernel.  demo_gemm_split_rows: the r demo_gemm would use
  * (0 = one launch); demo_gemm_set_split: largest leftover, in 256x256 tiles, that is split off (default 128, 0 = never). */
 int demo_gemm_split_rows(const demo_gemm_desc* d);
+/* Round 3: the dispatcher's whole plan for a descriptor -- rows[i] and kernel configuration cfg[i] (2566 = 256x256, 1282 = 128x128, 0 = the
+ * heuristic's single launch) of each part, in row order; returns the number of parts (1 = one launch).  Besides main + remainder there is an
+ * EQUAL-PARTS plan: full + 1 launches of the 256x256 kernel with at most one tile per CU each (a tile runs faster the fewer CUs are active:
+ * the main loop is bound by the chip-wide L2 -> LDS feed), taken when K <= the bound of demo_gemm_set_split_equal (0 = never, the default:
+ * measured -0.12 ms of a 35.7 ms training step at 1024, i.e. for the K = 768 products of N = 768, and slower on the long-K products). */
+int demo_gemm_split_plan(const demo_gemm_desc* d, int32_t* rows, int32_t* cfg, int32_t max_parts);
+int demo_gemm_set_split_equal(int max_k);
 int demo_gemm_set_pp_min_fill(int pct); /* tuning hook: least fill (%) of the last round of 256 CUs at which short-K products still take the 256x256 kernel (default 70) */
 int demo_gemm_set_pp_epilogue(int reg); /* tuning hook, 256x256 kernel: 1 (default) = epilogue straight from the accumulators, 0 = LDS-staged */
 int demo_gemm_set_split(int max_left_tiles);

@@ -258,6 +258,54 @@ def test_gemm_bf16_row_split_matches_single_launch():
     torch.testing.assert_close(outs[1], a.float().cpu() @ b.float().cpu().t() + bias.cpu(), rtol=1e-3, atol=1e-3)
 
 
+def test_gemm_bf16_equal_parts_plan():
+    """Round 3: a product whose 256^2 tile count leaves a partial last round is issued as full + 1 EQUAL launches of the 256^2 kernel
+    (demo_gemm_split_plan / demo_gemm_set_split_equal).  The plan of the training step's N = 768 shape, and the results of the plans --
+    one launch, main + remainder, equal parts -- on a shape with every epilogue operand that is offset per part (bf16 residual, second
+    output as D8 codes, act' operand as D8 codes)."""
+    import ctypes as C
+    from demo2_amd import _lib
+    from demo2_amd._lib import ACT_SAVED
+    lib = _lib.load()
+    # the plan itself (no launch): M = 49536, N = 768 -> 582 tiles = 2.27 rounds
+    d = _lib.GemmDesc()
+    x = torch.empty(16, device=DEV, dtype=torch.bfloat16)
+    d.A = d.B = d.C = x.data_ptr()
+    d.M, d.N, d.K = 49536, 768, 3072
+    d.a_rs, d.a_cs, d.b_rs, d.b_cs, d.c_rs = 3072, 1, 3072, 1, 768
+    d.dtA = d.dtB = d.dtC = _lib.BF16
+    d.alpha, d.batch1, d.batch2 = 1.0, 1, 1
+    rows, cfgs = (C.c_int32 * 4)(), (C.c_int32 * 4)()
+    lib.demo_gemm_set_split_equal(1024)                    # (the equal-parts plan is an opt-in hook: off by default)
+    assert lib.demo_gemm_split_plan(C.byref(d), rows, cfgs, 4) == 2                                   # long K: main + remainder
+    assert list(rows)[:2] == [170 * 256, 49536 - 170 * 256] and list(cfgs)[:2] == [2566, 1282]
+    d.K = 768                                              # short K: three equal launches
+    assert lib.demo_gemm_split_plan(C.byref(d), rows, cfgs, 4) == 3
+    assert list(rows)[:3] == [65 * 256, 65 * 256, 49536 - 130 * 256] and list(cfgs)[:3] == [2566] * 3
+    lib.demo_gemm_set_split_equal(0)
+    assert lib.demo_gemm_split_plan(C.byref(d), rows, cfgs, 4) == 2
+    M, N, K = 194 * 256 - 100, 768, 128
+    a, b, bias = rnd(M, K).bfloat16().to(DEV), rnd(N, K, seed=1, scale=K ** -0.5).bfloat16().to(DEV), rnd(N, seed=2).to(DEV)
+    res = rnd(M, N, seed=3).bfloat16().to(DEV)
+    outs = []
+    try:
+        for split, eq in ((0, 0), (128, 0), (128, 4096)):
+            lib.demo_gemm_set_split(split)
+            lib.demo_gemm_set_split_equal(eq)
+            y = ops.gemm(a, b, bias=bias, residual=res)
+            u, codes = ops.gemm(a, b, bias=bias, act=ACT_QUICKGELU, pre_out_new=True, pre_out_deriv=True, pre_out_d8=True)
+            g = ops.gemm(a, b, act_grad_pre=codes, act_grad_kind=ACT_SAVED)
+            outs.append((y.float().cpu(), u.float().cpu(), codes.cpu(), g.float().cpu()))
+    finally:
+        lib.demo_gemm_set_split(128)
+        lib.demo_gemm_set_split_equal(0)
+    for o in outs[1:]:
+        for t0, t1 in zip(outs[0], o):
+            assert torch.equal(t0, t1)                     # same kernels' arithmetic on every plan (the bias is the accumulators' initial value in both MFMA kernels)
+    ref = a.float().cpu() @ b.float().cpu().t() + bias.cpu() + res.float().cpu()
+    torch.testing.assert_close(outs[0][0], ref, rtol=2e-2, atol=2e-2)
+
+
 def test_gemm_bf16_batched_and_in_place_residual():
     Z, M, N, K = 3, 130, 128, 64
     A, B = rnd(Z, M, K).bfloat16(), rnd(Z, N, K, seed=1).bfloat16()
