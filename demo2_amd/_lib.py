@@ -42,6 +42,13 @@ class GemmDesc(C.Structure):
 
 _P, _I, _L, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 
+
+class TnItem(C.Structure):
+    """demo_tn_item (include/demo_hip.h): one weight-gradient product of a grouped launch."""
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("Mo", C.c_int32), ("No", C.c_int32),
+                ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("colsum", C.c_void_p)]
+
+
 # name -> argtypes (restype is int for all but demo_last_error); mirrors include/demo_hip.h
 PROTOTYPES = {
     "demo_abi_version": [],
@@ -97,6 +104,8 @@ PROTOTYPES = {
     "demo_atmoe_gate_softmax_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "demo_gemm_tn_bf16": [_P, _P, _P, _I, _I, _I, _L, _L, _L, _F, _I, _P, _P, _L, _P],
     "demo_gemm_tn_workspace": [_I, _I, _I],
+    "demo_gemm_tn_bf16_group": [C.POINTER(TnItem), _I, _I, _F, _I, _P, _L, _P],
+    "demo_gemm_tn_group_workspace": [C.POINTER(TnItem), _I, _I],
     "demo_attention_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "demo_embed_tokens_bwd": [_P, _P, _I, _F, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P],
     "demo_act_bwd": [_P, _P, _I, _P, _L, _P],
@@ -143,6 +152,7 @@ def load():
         fn.restype = C.c_int
     lib.demo_layernorm_bwd_workspace.restype = C.c_int64
     lib.demo_gemm_tn_workspace.restype = C.c_int64
+    lib.demo_gemm_tn_group_workspace.restype = C.c_int64
     lib.demo_atmoe_eval_part_elems.restype = C.c_int64
     lib.demo_last_error.argtypes = []
     lib.demo_last_error.restype = C.c_char_p

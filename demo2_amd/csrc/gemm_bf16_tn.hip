@@ -41,6 +41,14 @@ struct TArgs {
   float* partial;       // 256^2 form, optional: (splitk, Mo, No) workspace -> slices store plain partial tiles, summed by a 2nd pass
 };
 
+// Up to four products in ONE launch of the 256^2 form (demo_gemm_tn_bf16_group): the workgroups of product i are blockIdx.x in
+// [base[i], base[i+1]) (multiples of 8, so blockIdx & 7 stays the XCD id), longest reduction slices first.
+struct TGroup {
+  TArgs g[4];
+  int base[5];
+  int n;
+};
+
 // LDS-DMA staging of a full 64-row tile: rows [k0, k0+64) x cols [c0, c0+128)
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int64_t ld, int k0, int c0, char* lds_tile, int wave, int lane) {
 #pragma unroll
@@ -265,17 +273,24 @@ __device__ __forceinline__ bf16x8 pp_tr_frag(const char* base, int off) {
 }
 
 template <bool CS>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_tn_pp_kernel(const TArgs p) {
+__global__ __launch_bounds__(512, 1) void gemm_bf16_tn_pp_kernel(const TGroup grp) {
   __shared__ __attribute__((aligned(1024))) char smem[PSTAGES * PSTAGE_BYTES];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+  // which product of the launch this workgroup belongs to (wave-uniform; a single product is n = 1)
+  int gi = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+    if (k < grp.n && (int)blockIdx.x >= grp.base[k]) gi = k;
+  const TArgs& p = grp.g[gi];
+  const unsigned bid = blockIdx.x - (unsigned)grp.base[gi];
   // work map: items = split-major list of (split, tile); XCD x (= blockIdx & 7) takes the x-th run of consecutive items, i.e.
   // (mostly) one split: its ~32 co-resident workgroups read the same token rows of both operands through one L2.
   const int tiles = p.ntm * p.ntn, items = tiles * p.splitk;
   const int per = (items + 7) >> 3;
-  const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if ((int)(blockIdx.x >> 3) >= per || item >= items) return;
+  const int item = (bid & 7) * per + (bid >> 3);
+  if ((int)(bid >> 3) >= per || item >= items) return;
   const int split = item / tiles, tile = item - split * tiles;
   const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
   const int m0 = tm * PBM, n0 = tn * PBN;
@@ -497,7 +512,58 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
   for (int r = 0; r < 4; ++r) c[r * ldc] = accumulate ? c[r * ldc] + v[r] : v[r];
 }
 
+// the same for the products of a grouped launch: blocks [base[i], base[i+1]) reduce product i
+struct RGroup {
+  const float* partial[4];
+  float* C[4];
+  int64_t ldc[4];
+  int splitk[4], ntm[4], ntn[4];
+  int base[5];
+  int n, accumulate;
+};
+__global__ __launch_bounds__(256) void tn_reduce_group_kernel(const RGroup r) {
+  int gi = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+    if (k < r.n && (int)blockIdx.x >= r.base[k]) gi = k;
+  const int tiles = r.ntm[gi] * r.ntn[gi];
+  const int64_t q = (int64_t)(blockIdx.x - r.base[gi]) * 256 + threadIdx.x;
+  if (q >= (int64_t)tiles * (PBM * PBN / 4)) return;
+  const int tile = (int)(q >> 14), e = (int)(q & 16383);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* p4 = reinterpret_cast<const float4*>(r.partial[gi]) + q;
+  const int64_t slice4 = (int64_t)tiles * (PBM * PBN / 4);
+  const int splitk = r.splitk[gi];
+#pragma unroll 4
+  for (int k = 0; k < splitk; ++k) {
+    const float4 v = p4[k * slice4];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const int wave = e >> 11, i = (e >> 8) & 7, j = (e >> 6) & 3, lane = e & 63;
+  const int wr = wave >> 2, wc = wave & 3, g = lane >> 4, idx = lane & 15;
+  const int ntn = r.ntn[gi], tm = tile / ntn, tn = tile - tm * ntn;
+  const int m = tm * PBM + wr * 128 + ((i & 4) + ((i + wc) & 3)) * 16 + 4 * g;
+  const int n = tn * PBN + wc * 64 + j * 16 + idx;
+  const int64_t ldc = r.ldc[gi];
+  float* c = r.C[gi] + (int64_t)m * ldc + n;
+  const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) c[rr * ldc] = r.accumulate ? c[rr * ldc] + v[rr] : v[rr];
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// split-K plan of the 256^2 form for one product: slices so that the grid is about one round of the 256 CUs, at least 16 stages each
+inline void pp_plan(int Mo, int No, int Kr, int& ntm, int& ntn, int& splitk, int& kper) {
+  ntm = Mo / PBM; ntn = No / PBN;
+  const int tiles = ntm * ntn;
+  const int kstages = (Kr + PBK - 1) / PBK;
+  int sk = tiles >= 256 ? 1 : 256 / tiles;
+  if (sk > kstages / 16) sk = kstages / 16 > 0 ? kstages / 16 : 1;
+  const int per = (kstages + sk - 1) / sk;
+  kper = per * PBK;
+  splitk = (kstages + per - 1) / per;
+}
 
 }  // namespace
 
@@ -555,8 +621,13 @@ extern "C" int demo_gemm_tn_bf16(const void* A, const void* B, float* C, int32_t
       if (e != hipSuccess) DEMO_FAIL(-2, "demo_gemm_tn_bf16: memset failed: %s", hipGetErrorString(e));
     }
     const unsigned nwg = 8u * (unsigned)((tiles * p.splitk + 7) / 8);
-    if (colsum) hipLaunchKernelGGL(gemm_bf16_tn_pp_kernel<true>, dim3(nwg), dim3(512), 0, s, p);
-    else hipLaunchKernelGGL(gemm_bf16_tn_pp_kernel<false>, dim3(nwg), dim3(512), 0, s, p);
+    TGroup grp;
+    grp.g[0] = p;
+    grp.n = 1;
+    grp.base[0] = 0;
+    grp.base[1] = grp.base[2] = grp.base[3] = grp.base[4] = (int)nwg;
+    if (colsum) hipLaunchKernelGGL(gemm_bf16_tn_pp_kernel<true>, dim3(nwg), dim3(512), 0, s, grp);
+    else hipLaunchKernelGGL(gemm_bf16_tn_pp_kernel<false>, dim3(nwg), dim3(512), 0, s, grp);
     DEMO_LAUNCH_CHECK("demo_gemm_tn_bf16(256)");
     if (two_pass) {
       hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)cdiv64((int64_t)Mo * No / 4, 256)), dim3(256), 0, s, workspace, p.splitk, p.ntm, p.ntn, C,
@@ -587,5 +658,88 @@ extern "C" int demo_gemm_tn_bf16(const void* A, const void* B, float* C, int32_t
   const unsigned nwg = 8u * (unsigned)(((Pp + 7) / 8) * Qq * p.splitk);
   hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3(nwg), dim3(256), 0, s, p);
   DEMO_LAUNCH_CHECK("demo_gemm_tn_bf16");
+  return 0;
+}
+
+// ---- grouped launch (round 3) ----------------------------------------------------------------------------------------------------
+// The weight gradients of ONE transformer block -- dW of fc2, fc1, qkv and the output projection: the same 49536 reduction rows, four
+// operand pairs -- as ONE launch of the 256^2 form and ONE reduce launch.  Each product keeps its own split-K plan (so its workgroups
+// read the same token rows through one L2, as in the single launch); what changes is that the four grids are one grid, longest
+// slices first: the hardware starts a workgroup of the next product wherever one of the previous product retires, so (a) the tail of
+// every product (a last wave of workgroups on a few CUs), (b) its ~10 us burst of partial-tile stores -- a retiring wave does not wait
+// for its stores -- and (c) three launch ramps and three reduce launches disappear under the next product's main loop.
+// items[i]: A (Kr, Mo) / B (Kr, No) bf16 row-major with leading dimensions lda / ldb, C fp32 (Mo, No) with ldc, colsum (Mo) or NULL --
+// either every item has one or none.  Requires Mo, No multiples of 256 and Kr >= 2048 for every item (else -1: use demo_gemm_tn_bf16).
+extern "C" int64_t demo_gemm_tn_group_workspace(const demo_tn_item* items, int32_t n, int32_t Kr) {
+  if (!items || n < 1 || n > 4) return 0;
+  int64_t need = 0;
+  for (int i = 0; i < n; ++i) {
+    if (items[i].Mo <= 0 || items[i].No <= 0 || items[i].Mo % PBM || items[i].No % PBN || Kr < 2048) return 0;
+    int ntm, ntn, sk, kper;
+    pp_plan(items[i].Mo, items[i].No, Kr, ntm, ntn, sk, kper);
+    need += (int64_t)sk * items[i].Mo * items[i].No;
+  }
+  return need;
+}
+
+extern "C" int demo_gemm_tn_bf16_group(const demo_tn_item* items, int32_t n, int32_t Kr, float alpha, int32_t accumulate, float* workspace,
+                                       int64_t workspace_elems, void* stream) {
+  DEMO_REQUIRE(items && n >= 1 && n <= 4, "demo_gemm_tn_bf16_group: 1..4 items");
+  const int64_t need = demo_gemm_tn_group_workspace(items, n, Kr);
+  DEMO_REQUIRE(need > 0, "demo_gemm_tn_bf16_group: every item needs Mo, No multiples of 256 and Kr >= 2048");
+  DEMO_REQUIRE(workspace && workspace_elems >= need, "demo_gemm_tn_bf16_group: workspace of %lld floats required", (long long)need);
+  bool any_cs = false, all_cs = true;
+  for (int i = 0; i < n; ++i) {
+    DEMO_REQUIRE(items[i].A && items[i].B && items[i].C, "demo_gemm_tn_bf16_group: null operand in item %d", i);
+    DEMO_REQUIRE(items[i].lda % 8 == 0 && items[i].ldb % 8 == 0 && al16(items[i].A) && al16(items[i].B),
+                 "demo_gemm_tn_bf16_group: operands must be 16-B aligned with ld %% 8 == 0 (item %d)", i);
+    any_cs = any_cs || items[i].colsum != nullptr;
+    all_cs = all_cs && items[i].colsum != nullptr;
+  }
+  DEMO_REQUIRE(!any_cs || all_cs, "demo_gemm_tn_bf16_group: either every item has a colsum buffer or none");
+  hipStream_t s = (hipStream_t)stream;
+  // order: longest slices first
+  int order[4] = {0, 1, 2, 3}, stages[4] = {0, 0, 0, 0};
+  TArgs a[4];
+  int64_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    TArgs& p = a[i];
+    p.A = (const bf16_t*)items[i].A; p.B = (const bf16_t*)items[i].B; p.C = items[i].C;
+    p.Mo = items[i].Mo; p.No = items[i].No; p.Kr = Kr; p.lda = items[i].lda; p.ldb = items[i].ldb; p.ldc = items[i].ldc; p.alpha = alpha;
+    pp_plan(p.Mo, p.No, Kr, p.ntm, p.ntn, p.splitk, p.kper);
+    p.part_m = 0; p.use_atomics = 0; p.accumulate = accumulate; p.colsum = items[i].colsum;
+    p.partial = workspace + off;                            // (a product that is not split still goes through its one-slice image)
+    off += (int64_t)p.splitk * p.Mo * p.No;
+    stages[i] = p.kper;
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j)
+      if (stages[order[j]] > stages[order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+  TGroup grp;
+  RGroup red;
+  grp.n = red.n = n;
+  red.accumulate = accumulate;
+  int base = 0, rbase = 0;
+  for (int k = 0; k < 4; ++k) {
+    grp.base[k] = base;
+    red.base[k] = rbase;
+    if (k < n) {
+      const TArgs& p = a[order[k]];
+      grp.g[k] = p;
+      base += 8 * ((p.ntm * p.ntn * p.splitk + 7) / 8);
+      red.partial[k] = p.partial; red.C[k] = p.C; red.ldc[k] = p.ldc; red.splitk[k] = p.splitk; red.ntm[k] = p.ntm; red.ntn[k] = p.ntn;
+      rbase += (int)cdiv64((int64_t)p.Mo * p.No / 4, 256);
+    } else {
+      grp.g[k] = a[order[0]];
+      red.partial[k] = nullptr; red.C[k] = nullptr; red.ldc[k] = 0; red.splitk[k] = 0; red.ntm[k] = red.ntn[k] = 0;
+    }
+  }
+  grp.base[4] = base;
+  red.base[4] = rbase;
+  if (all_cs) hipLaunchKernelGGL(gemm_bf16_tn_pp_kernel<true>, dim3((unsigned)base), dim3(512), 0, s, grp);
+  else hipLaunchKernelGGL(gemm_bf16_tn_pp_kernel<false>, dim3((unsigned)base), dim3(512), 0, s, grp);
+  DEMO_LAUNCH_CHECK("demo_gemm_tn_bf16_group");
+  hipLaunchKernelGGL(tn_reduce_group_kernel, dim3((unsigned)rbase), dim3(256), 0, s, red);
+  DEMO_LAUNCH_CHECK("demo_gemm_tn_bf16_group(reduce)");
   return 0;
 }

@@ -434,12 +434,26 @@ def trunk_backward(m, tape, dtokens):
     # the kernels' own rates once they overlap, so the default stays single-stream.
     side = m.side_stream() if (lp and m.overlap_dw and not torch.cuda.is_current_stream_capturing()) else None
     main = torch.cuda.current_stream() if side is not None else None
-    dxbs = [dxb, torch.empty_like(dxb)] if side is not None else [dxb, dxb]    # the LayerNorm backward alternates its bf16 output
+    # Grouped weight gradients (round 3, bf16 gradient stream without the side stream): the four dW products of a block are issued as
+    # ONE launch at the end of the block's backward (ops.gemm_tn_group / demo_gemm_tn_bf16_group) -- their tails, partial-tile store
+    # bursts and launch ramps overlap instead of adding up.  Their dY operands must then outlive two LayerNorm backwards, so the
+    # bf16 gradient stream rotates through THREE buffers instead of being updated in place.  DEMO_GROUP_DW=0 restores one launch per Linear.
+    group_dw = bool(lps and side is None and m.group_dw)
+    dxbs = [dxb, torch.empty_like(dxb)] if side is not None else ([dxb, torch.empty_like(dxb), torch.empty_like(dxb)] if group_dw else [dxb, dxb])
     readers = [None, None]                                                      # last side-stream reader of each of them
     cur = 0
+    pending = []                                                                # this block's deferred (dY, X, weight key, ldc, bias key)
+
+    def flush_dw():
+        if pending:
+            ops.gemm_tn_group([(a_t, b_t, P.off(kw), ldc, P.off(kb)) for a_t, b_t, kw, ldc, kb in pending], G, accumulate=True)
+            pending.clear()
 
     def dw(a_t, b_t, key_w, ldc, key_b, buf=None):
         """dW (+ bias gradient) of one Linear; on the side stream when there is one."""
+        if group_dw:
+            pending.append((a_t, b_t, key_w, ldc, key_b))
+            return
         if side is None:
             ops.gemm_tn(a_t, b_t, G, out_off=P.off(key_w), ldc=ldc, accumulate=True, colsum_out=G, colsum_off=P.off(key_b))
             return
@@ -455,6 +469,9 @@ def trunk_backward(m, tape, dtokens):
     def next_dxb():
         """bf16 gradient buffer the next LayerNorm backward may overwrite: its last reader on the side stream has finished."""
         nonlocal cur
+        if group_dw:                            # three buffers in rotation: the two a block's deferred dW products still read stay intact
+            cur = (cur + 1) % 3
+            return dxbs[cur]
         cur ^= 1
         if side is not None and readers[cur] is not None:
             main.wait_event(readers[cur])
@@ -500,6 +517,7 @@ def trunk_backward(m, tape, dtokens):
         else:
             ops.layernorm_bwd(dh1, s["x"], P.f(k["ln1"] + ".weight"), s["mean1"], s["rstd1"], dx=dx, accumulate_dx=True,
                               dw=gw(k["ln1"] + ".weight"), db=gw(k["ln1"] + ".bias"), dx_lp=nb)
+        flush_dw()                                                  # the block's four weight gradients, one launch
         tape.blocks[i] = None                                       # release the activations of this block
         if sync is not None:
             if side is not None:

@@ -191,6 +191,9 @@ class DeMo(_Holder):
         # of bf16's own half-ulp on [0.5, 2)): the (tokens, 4W) tensor the MLP backward re-reads is 152 instead of 304 MB per block at
         # B = 128.  DEMO_ACT_DERIV_D8=0 keeps the derivative in bf16
         self.act_deriv_d8 = os.environ.get("DEMO_ACT_DERIV_D8", "1") != "0"
+        # bf16 mode: the four weight-gradient products of a transformer block as ONE grouped launch (hip_backward.trunk_backward);
+        # DEMO_GROUP_DW=0 restores one launch (and one summing launch) per Linear
+        self.group_dw = os.environ.get("DEMO_GROUP_DW", "1") != "0"
         self.geom = self._make_geometry(cfg)
         self._flatten()
 

@@ -644,6 +644,42 @@ def gemm_tn(a: Tensor, b: Tensor, out: Tensor, out_off: int = 0, ldc: Optional[i
                     accumulate=accumulate)
 
 
+def gemm_tn_group(items, out: Tensor, accumulate: bool = True, alpha: float = 1.0):
+    """Up to four weight-gradient products over the same reduction rows as ONE launch (demo_gemm_tn_bf16_group):
+    items = [(a (R, Mo), b (R, No), out_off, ldc, colsum_off or None), ...]; out_flat[out_off + m*ldc + n] (+)= sum_r a[r, m] b[r, n] and,
+    with colsum_off, out_flat[colsum_off + m] += sum_r a[r, m] (bias gradient).  Falls back to one gemm_tn per item when the group's
+    contract (bf16, Mo / No multiples of 256, R >= 2048, 16-B alignment, colsum for all or none) does not hold."""
+    lib = _lib.load()
+    R = items[0][0].shape[0]
+    ok = 1 <= len(items) <= 4 and R >= 2048 and out.dtype == torch.float32
+    cs_flags = [it[4] is not None for it in items]
+    ok = ok and (all(cs_flags) or not any(cs_flags))
+    for a, b, _, _, _ in items:
+        ok = ok and (a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.shape[0] == R and b.shape[0] == R and a.shape[1] % 256 == 0
+                     and b.shape[1] % 256 == 0 and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0
+                     and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+    if not ok:
+        for a, b, out_off, ldc, cs_off in items:
+            gemm_tn(a, b, out, out_off=out_off, ldc=ldc, alpha=alpha, accumulate=accumulate, colsum_out=out if cs_off is not None else None,
+                    colsum_off=cs_off or 0)
+        return out
+    _req_cuda(out, *[t for it in items for t in it[:2]])
+    arr = (_lib.TnItem * len(items))()
+    for i, (a, b, out_off, ldc, cs_off) in enumerate(items):
+        arr[i].A, arr[i].B, arr[i].C = a.data_ptr(), b.data_ptr(), out.data_ptr() + 4 * out_off
+        arr[i].Mo, arr[i].No = a.shape[1], b.shape[1]
+        arr[i].lda, arr[i].ldb, arr[i].ldc = a.stride(0), b.stride(0), ldc
+        arr[i].colsum = None if cs_off is None else out.data_ptr() + 4 * cs_off
+    need = int(lib.demo_gemm_tn_group_workspace(arr, len(items), R))
+    wkey = (out.device, _stream(), "group")
+    ws = _TN_WS.get(wkey)
+    if ws is None or ws.numel() < need:
+        ws = _TN_WS[wkey] = torch.empty(need, device=out.device, dtype=torch.float32)
+    check(lib.demo_gemm_tn_bf16_group(arr, len(items), R, float(alpha), int(accumulate), ws.data_ptr(), ws.numel(), _stream()),
+          "demo_gemm_tn_bf16_group")
+    return out
+
+
 def attention_bwd(qkv: Tensor, out: Tensor, dout: Tensor, lse: Tensor, Bn: int, L: int, H: int) -> Tensor:
     _req_cuda(qkv, out, dout, lse)
     assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and dout.dtype == qkv.dtype

@@ -270,6 +270,22 @@ int demo_gemm_tn_bf16(const void* A, const void* B, float* C, int32_t Mo, int32_
 int64_t demo_gemm_tn_workspace(int32_t Mo, int32_t No, int32_t Kr);
 /* colsum (optional, fp32 [Mo]): colsum[m] += sum_r A[r,m] -- the bias gradient of the same Linear, computed by the waves
  * that already hold the A fragments (no extra pass over dY). */
+/* Round 3: up to four such products over the SAME Kr reduction rows as one launch and one summing launch -- the weight gradients of
+ * one transformer block (solver step: engine/processor.py:99-104 consumes them all at once).  Each item keeps its own split of the
+ * reduction; the grids run as one, longest slices first, so every product's tail, its burst of partial-tile stores and three launch
+ * ramps disappear under the next product's main loop.  Mo, No multiples of 256 and Kr >= 2048 for every item; colsum for every item or
+ * for none; workspace of demo_gemm_tn_group_workspace floats (caller-owned, like every buffer). */
+typedef struct demo_tn_item {
+  const void* A;      /* (Kr, Mo) bf16, leading dimension lda */
+  const void* B;      /* (Kr, No) bf16, leading dimension ldb */
+  float* C;           /* (Mo, No) fp32, leading dimension ldc */
+  int32_t Mo, No;
+  int64_t lda, ldb, ldc;
+  float* colsum;      /* optional [Mo] */
+} demo_tn_item;
+int demo_gemm_tn_bf16_group(const demo_tn_item* items, int32_t n, int32_t Kr, float alpha, int32_t accumulate, float* workspace,
+                            int64_t workspace_elems, void* stream);
+int64_t demo_gemm_tn_group_workspace(const demo_tn_item* items, int32_t n, int32_t Kr);
 /* Self-attention backward (same packing as demo_attention_fwd; lse from the forward): dqkv (Bn*L, 3D). */
 int demo_layernorm_set_lp8(int on);    /* tuning hook: 1 (default) = demo_layernorm_bwd_lp takes the 8-column kernel when dy and x are both bf16 */
 int demo_attention_set_variant(int v); /* tuning hook: 1 (default) = forward with K/V only in LDS (4 workgroups per CU), 0 = the round-1 form */

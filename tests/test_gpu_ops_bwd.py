@@ -34,6 +34,40 @@ def test_gemm_tn_bf16_mfma(R, Mo, No):
     assert torch.equal(out3.cpu(), a2.t() @ b2)
 
 
+def test_gemm_tn_group_equals_single_launches():
+    """demo_gemm_tn_bf16_group: the weight gradients of a block (four Linears of different shapes over the same reduction rows, with
+    bias gradients, written at offsets of one flat buffer) as ONE launch equal the four single launches bit for bit (same kernel, same
+    split of the reduction, same summation order), and both equal the fp32 product; an item outside the group contract falls back."""
+    R, W = 4100, 256                                         # ragged reduction length: the last stage of every slice is partial
+    shapes = [(W, 4 * W), (4 * W, W), (3 * W, W), (W, W)]    # (Mo, No): fc2, fc1, qkv, proj in miniature
+    g = torch.Generator().manual_seed(0)
+    ops_ab = [((torch.randn(R, mo, generator=g) * 0.5).bfloat16().to(DEV), (torch.randn(R, no, generator=g) * 0.5).bfloat16().to(DEV)) for mo, no in shapes]
+    sizes = [mo * no for mo, no in shapes]
+    w_off = [sum(sizes[:i]) + 64 * i for i in range(4)]
+    b_off = [w_off[3] + sizes[3] + 64 + 2048 * i for i in range(4)]
+    n_flat = b_off[3] + 4096
+    base = torch.randn(n_flat, generator=g)
+    flat_g, flat_s = base.clone().to(DEV), base.clone().to(DEV)
+    ops.gemm_tn_group([(a, b, w_off[i], shapes[i][1], b_off[i]) for i, (a, b) in enumerate(ops_ab)], flat_g, accumulate=True)
+    for i, (a, b) in enumerate(ops_ab):
+        ops.gemm_tn(a, b, flat_s, out_off=w_off[i], ldc=shapes[i][1], accumulate=True, colsum_out=flat_s, colsum_off=b_off[i])
+    assert torch.equal(flat_g.cpu()[: w_off[3] + sizes[3]], flat_s.cpu()[: w_off[3] + sizes[3]])       # weights: identical sums
+    torch.testing.assert_close(flat_g.cpu(), flat_s.cpu(), rtol=1e-5, atol=1e-3)                        # bias gradients: fp32 atomics, any order
+    for i, (a, b) in enumerate(ops_ab):
+        mo, no = shapes[i]
+        want = base[w_off[i]: w_off[i] + mo * no].view(mo, no) + a.float().cpu().t() @ b.float().cpu()
+        torch.testing.assert_close(flat_g.cpu()[w_off[i]: w_off[i] + mo * no].view(mo, no), want, rtol=2e-3, atol=2e-3 * R ** 0.5)
+        torch.testing.assert_close(flat_g.cpu()[b_off[i]: b_off[i] + mo], base[b_off[i]: b_off[i] + mo] + a.float().cpu().sum(0), rtol=1e-3,
+                                   atol=1e-3 * R ** 0.5)
+    # untouched gaps of the flat buffer
+    assert torch.equal(flat_g.cpu()[w_off[0] + sizes[0]: w_off[1]], base[w_off[0] + sizes[0]: w_off[1]])
+    # fallback: an item with Mo = 128 is outside the 256^2 contract
+    a5, b5 = (torch.randn(R, 128, generator=g)).bfloat16().to(DEV), (torch.randn(R, 256, generator=g)).bfloat16().to(DEV)
+    out5 = torch.zeros(128 * 256, device=DEV)
+    ops.gemm_tn_group([(a5, b5, 0, 256, None)], out5, accumulate=False)
+    torch.testing.assert_close(out5.cpu().view(128, 256), a5.float().cpu().t() @ b5.float().cpu(), rtol=2e-3, atol=2e-3 * R ** 0.5)
+
+
 def test_gemm_tn_generic_and_offset():
     a, b = rnd(50, 33), rnd(50, 20, seed=1)
     flat = torch.zeros(4000, device=DEV)
