@@ -90,7 +90,8 @@ def gemm_roofline(model, step_fn):
                                        ("save_deriv_d8", d.pre_out and d.pre_out_kind == 2),
                                        ("bf16_residual" if d.dtRes == _lib.BF16 else "fp32_residual", d.residual),
                                        ("act_grad_d8" if d.dtPre == _lib.D8 else "act_grad", d.act_grad_pre), ("accumulate", d.accumulate)) if on) or "plain"
-        recs[path].append((e0, e1, 2.0 * d.M * d.N * d.K * nb, nbytes, (d.M, d.N, d.K, epi)))
+        fam = 1 if (d.pre_out or d.act_grad_pre) else 0        # the 256^2 kernel's epilogue family = its template instance (csrc/gemm_bf16.hip, pp_epi)
+        recs[path].append((e0, e1, 2.0 * d.M * d.N * d.K * nb, nbytes, (d.M, d.N, d.K, epi), fam))
         return rc
 
     class Wrapper:
@@ -132,7 +133,10 @@ def gemm_roofline(model, step_fn):
         torch.cuda.synchronize()
     finally:
         lib.demo_gemm = orig
-    names = {1: "gemm_bf16_nt_kernel<128,128,...>", 2: "gemm_bf16_nt_pp_kernel<true>"}
+    # the 256^2 kernel is ONE template compiled once per epilogue family (<true, 0>: bias / activation / residual; <true, 1>: the MLP's second
+    # output or act' operand) so that neither instance carries the other's variants: rocprofv3 lists the two instances as two rows,
+    # `instances` below gives each one's launches and average duration, the roofline figures cover both
+    names = {1: "gemm_bf16_nt_kernel<128,128,...>", 2: "gemm_bf16_nt_pp_kernel<true, *>"}
     stats = {}
     for path, rs in recs.items():
         if rs:
@@ -148,6 +152,11 @@ def gemm_roofline(model, step_fn):
                            "ms_per_step": round(ms, 3), "algorithmic_gflop_per_step": round(fl / 1e9, 1),
                            "achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 1),
                            "algorithmic_mb_per_launch": round(sum(r[3] for r in rs) / len(rs) / 1e6, 1),
+                           "instances": ({f"gemm_bf16_nt_pp_kernel<true, {f}>": {
+                               "launches_per_step": sum(1 for r in rs if r[5] == f),
+                               "avg_launch_us": round(sum(r[0].elapsed_time(r[1]) for r in rs if r[5] == f) * 1e3 / max(1, sum(1 for r in rs if r[5] == f)), 1),
+                               "tflops": round(sum(r[2] for r in rs if r[5] == f) / max(1e-9, sum(r[0].elapsed_time(r[1]) for r in rs if r[5] == f) * 1e-3) / 1e12, 1)}
+                               for f in (0, 1) if any(r[5] == f for r in rs)} if path == 2 else None),
                            # the same launches by product shape and epilogue (rows M of a split product = the part this kernel computes)
                            "by_shape": [{"M": k[0], "N": k[1], "K": k[2], "epilogue": k[3], "launches_per_step": v[0],
                                          "avg_launch_us": round(v[1] * 1e3 / v[0], 1), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
@@ -167,7 +176,12 @@ def gemm_roofline(model, step_fn):
         path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.json")))[-1]
         with open(path) as f:
             doc = json.load(f)
-        t = doc["kernels"].get(s["kernel"])
+        ks = doc["kernels"]
+        inst = [ks[k] for k in ks if k.startswith(s["kernel"].split("<")[0] + "<true")]     # every instance of the template
+        t = None
+        if inst:
+            n = sum(i["launches"] for i in inst)
+            t = {"hbm_mb_per_launch": round(sum(i["hbm_mb_per_launch"] * i["launches"] for i in inst) / n, 1)}
         if t and B_TRAFFIC_VALID[0]:
             traffic = {"hbm_mb_per_launch": t["hbm_mb_per_launch"], "algorithmic_mb_per_launch": s["algorithmic_mb_per_launch"],
                        "stale": doc.get("csrc_sha16") != csrc_sha16(),
@@ -181,7 +195,7 @@ def gemm_roofline(model, step_fn):
            "unit": "TFLOP/s", "frac": round(s["achieved_tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
            "launches_per_step": s["launches_per_step"], "avg_launch_us": s["avg_launch_us"],
            "gemm_ms_per_step": s["ms_per_step"], "algorithmic_gflop_per_step": s["algorithmic_gflop_per_step"],
-           "algorithmic_mb_per_launch": s["algorithmic_mb_per_launch"], "by_shape": s["by_shape"]}
+           "algorithmic_mb_per_launch": s["algorithmic_mb_per_launch"], "instances": s.get("instances"), "by_shape": s["by_shape"]}
     other = [v for k, v in stats.items() if k != dom]
     if other:
         out["other_mfma_nt_kernel"] = other[0]

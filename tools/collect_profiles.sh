@@ -12,7 +12,7 @@ step pmc fetch;            rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-fo
 step pmc write;            rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_W -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_W.log 2>&1 || echo FAILED
 python tools/pmc_traffic.py $O/pmc_F $O/pmc_W > $O/hbm_traffic_pmc.json || echo FAILED
 # the bench lines below read roofline.traffic from the newest profiles/r*_hbm_traffic_pmc.json: publish this pass's file first (ROUND=rNN)
-cp $O/hbm_traffic_pmc.json profiles/${ROUND:-r02}_hbm_traffic_pmc.json
+cp $O/hbm_traffic_pmc.json profiles/${ROUND:-r03}_hbm_traffic_pmc.json
 step bench default;        python bench.py > $O/bench_default.json 2> $O/bench_default.err || echo FAILED
 step kernel stats;         rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o t -- python3 bench.py > $O/bench_default_under_rocprof.json 2> $O/stats.err || echo FAILED
 step pmc l2 a;             rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_BUBBLE_sum --output-format csv -d $O/pmc_l2a -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_l2a.log 2>&1 || echo FAILED
@@ -27,6 +27,10 @@ step bench vit;            python bench.py --config vit --no-cpu-baseline > $O/b
 step bench dgaf;           python bench.py --fusion dgaf --no-cpu-baseline > $O/bench_dgaf.json 2> $O/bench_dgaf.err || echo FAILED
 step fwd B=1;              python bench.py --mode fwd --batch 1 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_fwd_b1.json 2>/dev/null || echo FAILED
 step gemm cost;            python tools/gemm_cost.py > $O/gemm_cost.txt 2>&1 || echo FAILED
+step vendor blas;          python tools/bench_blas_ref.py > $O/vendor_blas_reference.txt 2>&1 || echo FAILED
+step cu fill;              python tools/bench_cu_fill.py > $O/cu_fill.txt 2>&1 || echo FAILED
+step d8 accuracy;          python tools/probes/act_deriv_d8_accuracy.py > $O/act_deriv_d8_accuracy.txt 2>&1 || echo FAILED
+step tn;                   python tools/bench_gemm_tn.py > $O/bench_gemm_tn.txt 2>&1 || echo FAILED
 step attention;            python tools/bench_attn.py > $O/bench_attn.txt 2>&1 || echo FAILED
 step layernorm;            python tools/bench_ln.py > $O/bench_ln.txt 2>&1 || echo FAILED
 [ -x tools/probes/store_probe ] || hipcc --offload-arch=gfx950 -O3 tools/probes/store_probe.hip -o tools/probes/store_probe
