@@ -565,6 +565,33 @@ inline void pp_plan(int Mo, int No, int Kr, int& ntm, int& ntn, int& splitk, int
   splitk = (kstages + per - 1) / per;
 }
 
+// Split-K plan of a GROUP: ONE split count for every product (they share the reduction length, so all workgroups of the launch walk slices of
+// equal length and the products' grids tile the CUs without a ragged tail), chosen so that tiles x splits fills whole rounds of the 256 CUs with
+// the FEWEST slices: the four products of a trunk block (108 tiles) take 7 slices each = 756 workgroups = 2.95 rounds, against 252 + 252 + 243 +
+// 252 = 999 workgroups of four different lengths under the per-product plans -- a quarter fewer partial tiles to store and to sum.
+inline int group_split(int total_tiles, int Kr) {
+  const int kstages = (Kr + PBK - 1) / PBK;
+  int best = 1;
+  double best_eff = 0.0;
+  for (int R = 1; R <= 8; ++R) {
+    int sk = 256 * R / total_tiles;
+    if (sk < 1) continue;
+    if (sk > kstages / 16) sk = kstages / 16 > 0 ? kstages / 16 : 1;      // at least 16 stages per workgroup
+    const double wgs = (double)total_tiles * sk;
+    const double eff = wgs / (256.0 * (int)((wgs + 255.0) / 256.0));
+    if (eff > best_eff + 0.02) { best_eff = eff; best = sk; }              // a later (larger) plan must be clearly fuller to be taken
+    if (best_eff >= 0.95) break;
+  }
+  return best;
+}
+inline void pp_plan_fixed(int Mo, int No, int Kr, int sk, int& ntm, int& ntn, int& splitk, int& kper) {
+  ntm = Mo / PBM; ntn = No / PBN;
+  const int kstages = (Kr + PBK - 1) / PBK;
+  const int per = (kstages + sk - 1) / sk;
+  kper = per * PBK;
+  splitk = (kstages + per - 1) / per;
+}
+
 }  // namespace
 
 static int g_tn_force = 0;     // bench hook (shared with demo_gemm_force_tile): 128 forces the 128^2 form
@@ -673,10 +700,16 @@ extern "C" int demo_gemm_tn_bf16(const void* A, const void* B, float* C, int32_t
 extern "C" int64_t demo_gemm_tn_group_workspace(const demo_tn_item* items, int32_t n, int32_t Kr) {
   if (!items || n < 1 || n > 4) return 0;
   int64_t need = 0;
+  int total_tiles = 0;
   for (int i = 0; i < n; ++i) {
     if (items[i].Mo <= 0 || items[i].No <= 0 || items[i].Mo % PBM || items[i].No % PBN || Kr < 2048) return 0;
+    total_tiles += (items[i].Mo / PBM) * (items[i].No / PBN);
+  }
+  const int gsk = n > 1 ? group_split(total_tiles, Kr) : 0;
+  for (int i = 0; i < n; ++i) {
     int ntm, ntn, sk, kper;
-    pp_plan(items[i].Mo, items[i].No, Kr, ntm, ntn, sk, kper);
+    if (n > 1) pp_plan_fixed(items[i].Mo, items[i].No, Kr, gsk, ntm, ntn, sk, kper);
+    else pp_plan(items[i].Mo, items[i].No, Kr, ntm, ntn, sk, kper);
     need += (int64_t)sk * items[i].Mo * items[i].No;
   }
   return need;
@@ -702,11 +735,15 @@ extern "C" int demo_gemm_tn_bf16_group(const demo_tn_item* items, int32_t n, int
   int order[4] = {0, 1, 2, 3}, stages[4] = {0, 0, 0, 0};
   TArgs a[4];
   int64_t off = 0;
+  int total_tiles = 0;
+  for (int i = 0; i < n; ++i) total_tiles += (items[i].Mo / PBM) * (items[i].No / PBN);
+  const int gsk = n > 1 ? group_split(total_tiles, Kr) : 0;
   for (int i = 0; i < n; ++i) {
     TArgs& p = a[i];
     p.A = (const bf16_t*)items[i].A; p.B = (const bf16_t*)items[i].B; p.C = items[i].C;
     p.Mo = items[i].Mo; p.No = items[i].No; p.Kr = Kr; p.lda = items[i].lda; p.ldb = items[i].ldb; p.ldc = items[i].ldc; p.alpha = alpha;
-    pp_plan(p.Mo, p.No, Kr, p.ntm, p.ntn, p.splitk, p.kper);
+    if (n > 1) pp_plan_fixed(p.Mo, p.No, Kr, gsk, p.ntm, p.ntn, p.splitk, p.kper);
+    else pp_plan(p.Mo, p.No, Kr, p.ntm, p.ntn, p.splitk, p.kper);
     p.part_m = 0; p.use_atomics = 0; p.accumulate = accumulate; p.colsum = items[i].colsum;
     p.partial = workspace + off;                            // (a product that is not split still goes through its one-slice image)
     off += (int64_t)p.splitk * p.Mo * p.No;

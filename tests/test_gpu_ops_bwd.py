@@ -36,8 +36,8 @@ def test_gemm_tn_bf16_mfma(R, Mo, No):
 
 def test_gemm_tn_group_equals_single_launches():
     """demo_gemm_tn_bf16_group: the weight gradients of a block (four Linears of different shapes over the same reduction rows, with
-    bias gradients, written at offsets of one flat buffer) as ONE launch equal the four single launches bit for bit (same kernel, same
-    split of the reduction, same summation order), and both equal the fp32 product; an item outside the group contract falls back."""
+    bias gradients, written at offsets of one flat buffer) as ONE launch equal the four single launches to fp32 summation order (same
+    kernel; the group has its own split of the reduction), and both equal the fp32 product; an item outside the group contract falls back."""
     R, W = 4100, 256                                         # ragged reduction length: the last stage of every slice is partial
     shapes = [(W, 4 * W), (4 * W, W), (3 * W, W), (W, W)]    # (Mo, No): fc2, fc1, qkv, proj in miniature
     g = torch.Generator().manual_seed(0)
@@ -51,8 +51,9 @@ def test_gemm_tn_group_equals_single_launches():
     ops.gemm_tn_group([(a, b, w_off[i], shapes[i][1], b_off[i]) for i, (a, b) in enumerate(ops_ab)], flat_g, accumulate=True)
     for i, (a, b) in enumerate(ops_ab):
         ops.gemm_tn(a, b, flat_s, out_off=w_off[i], ldc=shapes[i][1], accumulate=True, colsum_out=flat_s, colsum_off=b_off[i])
-    assert torch.equal(flat_g.cpu()[: w_off[3] + sizes[3]], flat_s.cpu()[: w_off[3] + sizes[3]])       # weights: identical sums
-    torch.testing.assert_close(flat_g.cpu(), flat_s.cpu(), rtol=1e-5, atol=1e-3)                        # bias gradients: fp32 atomics, any order
+    # same kernel and arithmetic; the group cuts the reduction into its own number of slices (one count for all products), so the fp32 sums
+    # differ from the single launches' in their order only
+    torch.testing.assert_close(flat_g.cpu(), flat_s.cpu(), rtol=1e-5, atol=2e-3)
     for i, (a, b) in enumerate(ops_ab):
         mo, no = shapes[i]
         want = base[w_off[i]: w_off[i] + mo * no].view(mo, no) + a.float().cpu().t() @ b.float().cpu()
