@@ -1368,6 +1368,8 @@ int demo_gemm_bf16_eligible(const demo_gemm_desc& d) {
 static int g_force_tile = 0;   // test/bench hook: 128 or 256 forces a configuration, 0 = heuristic
 static int g_pp_reg_epi = 1;   // 256^2 kernel: 1 = register epilogue over permuted weight rows, 0 = LDS-staged row-major epilogue
 static int g_pp_min_eff_pct = 70;
+static int g_group_m = 0;      // 256^2 kernel, tuning hook: row panels per tile-order group (0 = heuristic)
+extern "C" int demo_gemm_set_group_m(int g) { g_group_m = g < 0 ? 0 : g; return 0; }
 static int g_dephase = 0;
 extern "C" int demo_gemm_set_dephase(int units) { g_dephase = units < 0 ? 0 : units; return 0; }
 static int g_epi_stage = 1;
@@ -1580,7 +1582,12 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
     case 2566:
       p.ntm = (int)cdiv64(d.M, 256);
       p.ntn = d.N / 256;
-      p.group_m = 32 / p.ntn < 1 ? 1 : (32 / p.ntn > 8 ? 8 : 32 / p.ntn);      // (2..8 measured within 1 % of each other)
+      // Row panels per group of the tile order.  An XCD's ~32 concurrent tiles cover gm row panels x 32/gm weight panels and fetch gm + 32/gm
+      // operand panels per wave of tiles: 18 at gm = 2 (round 2's 32 / ntn for N = 3072), 11.3 at gm = 6.  Round 2 measured 2..8 within 1 % per
+      // product in isolation; inside the training step (interleaved runs, two boxes) gm = 6 for every product is 0.33 ms faster than
+      // 32 / ntn (34.86 -> 34.53 ms; 5 / 7 / 12: 34.70 / 34.73 / 35.02) and the kernel's L2 fills drop 11 % (family 1) / 5 % (family 0).
+      p.group_m = p.ntn >= 3 ? 6 : (32 / p.ntn > 8 ? 8 : 32 / p.ntn);
+      if (g_group_m > 0) p.group_m = g_group_m;                                  // tuning hook (demo_gemm_set_group_m, DEMO_GEMM_GROUP_M)
       {
         unsigned grid = (unsigned)(p.ntm * p.ntn);
         p.colslice = 0;
