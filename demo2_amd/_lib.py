@@ -63,6 +63,7 @@ PROTOTYPES = {
     "demo_gemm_set_pp_epilogue": [C.c_int],
     "demo_gemm_set_pp_min_fill": [C.c_int],
     "demo_gemm_set_dephase": [C.c_int],
+    "demo_gemm_set_reverse_m": [C.c_int],
     "demo_gemm_set_group_m": [C.c_int],
     "demo_gemm_generic_tile": [C.c_int],
     "demo_gemm_set_colslice": [C.c_int],
@@ -170,6 +171,8 @@ def load():
         lib.demo_gemm_set_split_equal(int(os.environ["DEMO_GEMM_SPLIT_EQUAL"]))   # partial-round products as equal 256^2 launches up to this K (0 = never)
     if "DEMO_GEMM_GROUP_M" in os.environ:
         lib.demo_gemm_set_group_m(int(os.environ["DEMO_GEMM_GROUP_M"]))         # 256x256 kernel: row panels per tile-order group
+    if "DEMO_GEMM_REVERSE_M" in os.environ:
+        lib.demo_gemm_set_reverse_m(int(os.environ["DEMO_GEMM_REVERSE_M"]))     # 256x256 kernel: reverse row-panel walk from this K
     if "DEMO_GENERIC_TILE" in os.environ:
         lib.demo_gemm_generic_tile(int(os.environ["DEMO_GENERIC_TILE"]))        # generic fp32 kernel: 32 / 64 forced (0 = heuristic)
     if "DEMO_GEMM_DEPHASE" in os.environ:

@@ -42,6 +42,7 @@ struct FArgs {
   int dephase;                 // 256^2 kernel, tuning hook: first-round workgroups start ((id >> 3) & 3) * dephase * 64 clocks late
   int epi_stage;               // 256^2 kernel, register epilogue: bf16 outputs leave through an LDS image of the tile (whole-row stores)
   int colslice;                // 256^2 kernel: > 1 = every XCD keeps to ntn / colslice weight panels for the whole launch (see the kernel)
+  int rev_m;                   // 256^2 kernel, tuning hook: walk the row panels last to first (the rows the producer kernel wrote last come first)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -995,6 +996,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_pp_kernel(const FArgs p) 
     m0 = (gm0 + in_grp % gsz) * BM;
     n0 = (in_grp / gsz) * BN;
   }
+  if (p.rev_m) m0 = (p.ntm - 1) * BM - m0;
   const int z = blockIdx.y;
   const bf16_t* A = p.A + z * p.sA;
   const bf16_t* B = p.B + z * p.sB;
@@ -1368,6 +1370,8 @@ int demo_gemm_bf16_eligible(const demo_gemm_desc& d) {
 static int g_force_tile = 0;   // test/bench hook: 128 or 256 forces a configuration, 0 = heuristic
 static int g_pp_reg_epi = 1;   // 256^2 kernel: 1 = register epilogue over permuted weight rows, 0 = LDS-staged row-major epilogue
 static int g_pp_min_eff_pct = 70;
+static int g_rev_m_min_k = 0;  // 256^2 kernel, tuning hook: products with K >= this walk their row panels in reverse (0 = never)
+extern "C" int demo_gemm_set_reverse_m(int min_k) { g_rev_m_min_k = min_k < 0 ? 0 : min_k; return 0; }
 static int g_group_m = 0;      // 256^2 kernel, tuning hook: row panels per tile-order group (0 = heuristic)
 extern "C" int demo_gemm_set_group_m(int g) { g_group_m = g < 0 ? 0 : g; return 0; }
 static int g_dephase = 0;
@@ -1533,7 +1537,11 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
       return rc;
     }
     int rc = 0;
-    for (int i = 0; i < nparts && rc == 0; ++i) rc = demo_gemm_bf16_launch(part[i], s, pcfg[i]);
+    const bool last_first = g_rev_m_min_k > 0 && d.K >= g_rev_m_min_k;     // (reverse-walk hook: the rows the producer wrote last go first)
+    for (int i = 0; i < nparts && rc == 0; ++i) {
+      const int j = last_first ? nparts - 1 - i : i;
+      rc = demo_gemm_bf16_launch(part[j], s, pcfg[j]);
+    }
     return rc;
   }
   FArgs p;
@@ -1547,6 +1555,7 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
   p.pre_out_kind = d.pre_out ? d.pre_out_kind : 0;
   p.dtRes = d.residual ? d.dtRes : 0;
   p.dephase = g_dephase;
+  p.rev_m = g_rev_m_min_k > 0 && d.K >= g_rev_m_min_k;
   p.colslice = 0;
   p.epi_stage = g_epi_stage;
   p.M = d.M; p.N = d.N; p.K = d.K;

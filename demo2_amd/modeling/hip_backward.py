@@ -446,7 +446,8 @@ def trunk_backward(m, tape, dtokens):
 
     def flush_dw():
         if pending:
-            ops.gemm_tn_group([(a_t, b_t, P.off(kw), ldc, P.off(kb)) for a_t, b_t, kw, ldc, kb in pending], G, accumulate=True)
+            order = reversed(pending) if m.group_dw_fresh_first else pending
+            ops.gemm_tn_group([(a_t, b_t, P.off(kw), ldc, P.off(kb)) for a_t, b_t, kw, ldc, kb in order], G, accumulate=True)
             pending.clear()
 
     def dw(a_t, b_t, key_w, ldc, key_b, buf=None):

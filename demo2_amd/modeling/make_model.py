@@ -194,6 +194,9 @@ class DeMo(_Holder):
         # bf16 mode: the four weight-gradient products of a transformer block as ONE grouped launch (hip_backward.trunk_backward);
         # DEMO_GROUP_DW=0 restores one launch (and one summing launch) per Linear
         self.group_dw = os.environ.get("DEMO_GROUP_DW", "1") != "0"
+        # order of the products inside the grouped launch: freshest operands first (qkv, proj, fc1, fc2: the attention backward's output was written
+        # last and is still in the Infinity Cache) or in the order the backward produced them
+        self.group_dw_fresh_first = os.environ.get("DEMO_GROUP_DW_ORDER", "produced") == "fresh"
         self.geom = self._make_geometry(cfg)
         self._flatten()
 

@@ -99,6 +99,7 @@ int demo_gemm_set_split_overlap(int on); /* row-split products: 1 = the remainde
 int demo_gemm_set_epi_stage(int on);  /* 256x256 kernel, bf16 outputs: 1 (default) = whole-row stores through an LDS image of the output tile, 0 = 16-row x 64-B stores straight from the accumulator layout */
 int demo_gemm_set_colslice(int s);   /* tuning hook, 256x256 kernel: 2 / 4 / 8 = every XCD keeps to N / 256 / s weight panels for the whole launch; 0 = heuristic, 1 = off */
 int demo_gemm_set_group_m(int g);     /* tuning hook, 256x256 kernel: row panels per group of the XCD-aware tile order (0 = heuristic) */
+int demo_gemm_set_reverse_m(int min_k); /* tuning hook, 256x256 kernel: products with K >= min_k walk their row panels last to first (0 = never, the default) */
 int demo_gemm_set_dephase(int units); /* tuning hook, 256x256 kernel: first-round workgroups start ((id >> 3) & 3) * units * 64 clocks late (default 0) */
 int demo_gemm_store_policy(void); /* cache policy the MFMA NT kernels' output stores were BUILT with (-DDEMO_STORE_POL): 0 default, 1 nt, 2 sc1 (write-through) */
 int demo_gemm_desc_size(void); /* sizeof(demo_gemm_desc): lets a foreign binding verify its struct layout */
