@@ -28,6 +28,40 @@ __global__ __launch_bounds__(256) void embed_tokens_bwd_kernel(const float* __re
   const int t = blockIdx.x, L = np + 1;
   const int per = (Bn + gridDim.y - 1) / gridDim.y;
   const int b0 = blockIdx.y * per, b1 = min(Bn, b0 + per);
+  if ((W & 3) == 0) {
+    // four consecutive channels per thread (16-B loads, 8-B bf16 stores), four images in flight: the scalar form below walks its slab's
+    // images one dependent 4-B load at a time (115 us for 228 MB at B = 128)
+    for (int c = threadIdx.x * 4; c < W; c += blockDim.x * 4) {
+      float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int bb = b0; bb < b1; bb += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          v[u] = bb + u < b1 ? *reinterpret_cast<const float4*>(dpre + ((int64_t)(bb + u) * L + t) * W + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int b = bb + u;
+          if (b >= b1) break;
+          s4.x += v[u].x; s4.y += v[u].y; s4.z += v[u].z; s4.w += v[u].w;
+          if (t > 0) io<TP>::st4(dpatch + ((int64_t)b * np + (t - 1)) * W + c, v[u]);
+          if (dcam && cam && (cam_all || t == 0)) {
+            const int64_t ci = cam[b];
+            if (ci >= 0 && ci < n_cam) {
+              float* dc = dcam + ci * (int64_t)W + c;
+              atomicAdd(dc, cam_scale * v[u].x); atomicAdd(dc + 1, cam_scale * v[u].y);
+              atomicAdd(dc + 2, cam_scale * v[u].z); atomicAdd(dc + 3, cam_scale * v[u].w);
+            } else if (err && c == 0) atomicOr(err, DEMO_ERR_CAM_RANGE);       // out of range: nothing is written (demo_hip.h)
+          }
+        }
+      }
+      if (dpos) {
+        float* dp = dpos + (int64_t)t * W + c;
+        atomicAdd(dp, s4.x); atomicAdd(dp + 1, s4.y); atomicAdd(dp + 2, s4.z); atomicAdd(dp + 3, s4.w);
+      }
+      if (t == 0 && dcls) { atomicAdd(dcls + c, s4.x); atomicAdd(dcls + c + 1, s4.y); atomicAdd(dcls + c + 2, s4.z); atomicAdd(dcls + c + 3, s4.w); }
+    }
+    return;
+  }
   for (int c = threadIdx.x; c < W; c += blockDim.x) {
     float s = 0.f;
     for (int b = b0; b < b1; ++b) {
@@ -415,7 +449,9 @@ __global__ __launch_bounds__(256) void tokens_grad_kernel(const float* __restric
                                                           T* __restrict__ out, int L, int C) {
   const int b = blockIdx.x;
   const float inv = 1.f / (float)(L - 1);
-  for (int i = threadIdx.x; i < L * (C >> 2); i += blockDim.x) {
+  // blockIdx.y: slice of the token rows (a grid of Bn workgroups alone leaves half the CUs idle at B = 128)
+  const int lper = (L + gridDim.y - 1) / gridDim.y, l0 = blockIdx.y * lper, l1 = min(L, l0 + lper);
+  for (int i = l0 * (C >> 2) + threadIdx.x; i < l1 * (C >> 2); i += blockDim.x) {
     const int l = i / (C >> 2), c4 = (i - l * (C >> 2)) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (dtok && (l > 0 || keep_row0)) v = *reinterpret_cast<const float4*>(dtok + ((int64_t)b * L + l) * C + c4);
@@ -622,9 +658,9 @@ extern "C" int demo_tokens_grad(const float* dtok, const float* dcls, int64_t cl
   DEMO_REQUIRE(C % 4 == 0 && L >= 2, "demo_tokens_grad: bad shape");
   hipStream_t s = (hipStream_t)stream;
   if (dt == DEMO_BF16)
-    hipLaunchKernelGGL(tokens_grad_kernel<bf16_t>, dim3(Bn), dim3(256), 0, s, dtok, dcls, cls_ld, dmean, mean_ld, keep_row0, (bf16_t*)out, L, C);
+    hipLaunchKernelGGL(tokens_grad_kernel<bf16_t>, dim3(Bn, Bn >= 1024 ? 1 : 8), dim3(256), 0, s, dtok, dcls, cls_ld, dmean, mean_ld, keep_row0, (bf16_t*)out, L, C);
   else
-    hipLaunchKernelGGL(tokens_grad_kernel<float>, dim3(Bn), dim3(256), 0, s, dtok, dcls, cls_ld, dmean, mean_ld, keep_row0, (float*)out, L, C);
+    hipLaunchKernelGGL(tokens_grad_kernel<float>, dim3(Bn, Bn >= 1024 ? 1 : 8), dim3(256), 0, s, dtok, dcls, cls_ld, dmean, mean_ld, keep_row0, (float*)out, L, C);
   DEMO_LAUNCH_CHECK("demo_tokens_grad");
   return 0;
 }
