@@ -414,17 +414,21 @@ __global__ __launch_bounds__(256) void hdm_vbias_bwd_kernel(const float* __restr
                                                             const float* __restrict__ psum, float* __restrict__ dbias,
                                                             float* __restrict__ dpsum, int Bs, int C, int Hh) {
   const int dh = C / Hh;
-  if (blockIdx.x < 7) {
-    const int br = blockIdx.x;
+  constexpr int SLABS = 8;                 // dbias: 7 branches x SLABS sample slabs, combined with fp32 atomics (one block per branch walked all
+                                           // samples with one dependent load each: 52 us at B = 128)
+  if (blockIdx.x < 7 * SLABS) {
+    const int br = blockIdx.x % 7, slab = blockIdx.x / 7;
+    const int per = (Bs + SLABS - 1) / SLABS, b0 = slab * per, b1 = min(Bs, b0 + per);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       float s = 0.f;
-      for (int b = 0; b < Bs; ++b) s = fmaf(dy[((int64_t)b * 7 + br) * C + c], psum[((int64_t)b * 7 + br) * Hh + c / dh], s);
-      dbias[br * bias_stride + c] += s;
+#pragma unroll 4
+      for (int b = b0; b < b1; ++b) s = fmaf(dy[((int64_t)b * 7 + br) * C + c], psum[((int64_t)b * 7 + br) * Hh + c / dh], s);
+      atomicAdd(&dbias[br * bias_stride + c], s);
     }
     return;
   }
   const int lane = threadIdx.x & 63;
-  const int64_t item = (int64_t)(blockIdx.x - 7) * 4 + (threadIdx.x >> 6);       // (b*7 + br)*Hh + h
+  const int64_t item = (int64_t)(blockIdx.x - 7 * SLABS) * 4 + (threadIdx.x >> 6);       // (b*7 + br)*Hh + h
   if (item >= (int64_t)Bs * 7 * Hh) return;
   const int h = (int)(item % Hh);
   const int64_t bb = item / Hh;
@@ -641,7 +645,7 @@ extern "C" int demo_hdm_softmax_pool_bwd(const float* dpooled, const float* dpsu
 
 extern "C" int demo_hdm_vbias_bwd(const float* dy, const float* bias, int64_t bias_stride, const float* psum, float* dbias, float* dpsum,
                                   int32_t Bs, int32_t C, int32_t Hh, void* stream) {
-  const unsigned nblk = 7 + (unsigned)cdiv64((int64_t)Bs * 7 * Hh, 4);
+  const unsigned nblk = 7 * 8 + (unsigned)cdiv64((int64_t)Bs * 7 * Hh, 4);      // (8 = SLABS of the kernel)
   hipLaunchKernelGGL(hdm_vbias_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, bias, bias_stride, psum, dbias, dpsum, Bs, C, Hh);
   DEMO_LAUNCH_CHECK("demo_hdm_vbias_bwd");
   return 0;
