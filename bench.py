@@ -136,7 +136,7 @@ def gemm_roofline(model, step_fn):
     # the 256^2 kernel is ONE template compiled once per epilogue family (<true, 0>: bias / activation / residual; <true, 1>: the MLP's second
     # output or act' operand) so that neither instance carries the other's variants: rocprofv3 lists the two instances as two rows,
     # `instances` below gives each one's launches and average duration, the roofline figures cover both
-    names = {1: "gemm_bf16_nt_kernel<128,128,...>", 2: "gemm_bf16_nt_pp_kernel<true, *>"}
+    names = {1: "gemm_bf16_nt_kernel<128,128,...> / <160,128,...,3> (row-split remainders, small products)", 2: "gemm_bf16_nt_pp_kernel<true, *>"}
     stats = {}
     for path, rs in recs.items():
         if rs:

@@ -59,6 +59,7 @@ PROTOTYPES = {
     "demo_gemm_split_rows": [C.POINTER(GemmDesc)],
     "demo_gemm_split_plan": [C.POINTER(GemmDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32],
     "demo_gemm_set_split_equal": [C.c_int],
+    "demo_gemm_set_rem160": [C.c_int],
     "demo_gemm_set_split": [C.c_int],
     "demo_gemm_set_pp_epilogue": [C.c_int],
     "demo_gemm_set_pp_min_fill": [C.c_int],
@@ -173,6 +174,8 @@ def load():
         lib.demo_gemm_set_group_m(int(os.environ["DEMO_GEMM_GROUP_M"]))         # 256x256 kernel: row panels per tile-order group
     if "DEMO_GEMM_REVERSE_M" in os.environ:
         lib.demo_gemm_set_reverse_m(int(os.environ["DEMO_GEMM_REVERSE_M"]))     # 256x256 kernel: reverse row-panel walk from this K
+    if "DEMO_GEMM_REM160" in os.environ:
+        lib.demo_gemm_set_rem160(int(os.environ["DEMO_GEMM_REM160"]))           # 0: row-split remainders always on the 128x128 kernel
     if "DEMO_GENERIC_TILE" in os.environ:
         lib.demo_gemm_generic_tile(int(os.environ["DEMO_GENERIC_TILE"]))        # generic fp32 kernel: 32 / 64 forced (0 = heuristic)
     if "DEMO_GEMM_DEPHASE" in os.environ:

@@ -683,11 +683,18 @@ __device__ __forceinline__ void lds_read2(bf16x8 (&f)[2], unsigned base) {
                : "memory");
 }
 
+// one ds_read_b128 at a compile-time byte offset from a base; NOT waited for here
+template <int OFF> __device__ __forceinline__ void lds_read1(bf16x8& f, unsigned base) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f) : "v"(base), "n"(OFF) : "memory");
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
@@ -824,6 +831,36 @@ void gemm_bf16_nt_kernel(const FArgs p) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[1][j], af[1][i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+    } else if constexpr (TM == 5 && TN == 4) {
+      // 160 x 128 tile (the row-split remainders: 3 LDS buffers, two K-tiles in flight): the 18 fragment reads of the K-step as inline asm --
+      // a compiler-visible LDS load is ordered behind the pending LDS-DMA writes with vmcnt(0), which would drain the tiles in flight
+      bf16x8 af[2][4], a5[2], bfr[2][4];              // row tiles 0..3 and row tile 4 of the wave, both k-halves
+      const unsigned ab0 = lds_off(la + foff0), ab1 = lds_off(la + foff1);
+      const unsigned bb0 = lds_off(lb + foff0), bb1 = lds_off(lb + foff1);
+      lds_read4(bfr[0], bb0);
+      lds_read4(af[0], ab0);
+      lds_read1<8192>(a5[0], ab0);
+      lds_read4(bfr[1], bb1);
+      lds_read4(af[1], ab1);
+      lds_read1<8192>(a5[1], ab1);
+      asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[4][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], a5[kk], acc[4][j], 0, 0, 0);
+        if (kk == 0) {
+          __builtin_amdgcn_sched_barrier(0);          // keep k-half 0's MFMAs above the wait for k-half 1
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     } else if constexpr (TM == 2 && TN == 2) {
       // 64^2 tile: the eight fragment reads as inline asm (a compiler-visible LDS load is ordered behind the LDS-DMA writes with
       // vmcnt(0), which would drain the three K-tiles kept in flight)
@@ -901,7 +938,7 @@ void gemm_bf16_nt_kernel(const FArgs p) {
       }
     }
     __syncthreads();
-    epi_rows<NIT, RSTEP, BN, (NIT < 4 ? NIT : 4)>(p, ct, threadIdx.x / CPR, m0, n0 + c * 8, c, bz0, bz1, coff, epre, have_epre);
+    epi_rows<NIT, RSTEP, BN, (NIT < 4 ? NIT : (NIT % 4 == 0 ? 4 : 2))>(p, ct, threadIdx.x / CPR, m0, n0 + c * 8, c, bz0, bz1, coff, epre, have_epre);
   } else {
     // direct form: lane holds C[m][n .. n+3] for each of its MFMA tiles
     const int ng = (lane >> 4) * 4;
@@ -1435,6 +1472,8 @@ int demo_gemm_bf16_config(const demo_gemm_desc& d) {
 // demo_gemm_bf16_split_plan: rows[i] of each part (multiples of 256 but the last) and its kernel configuration; returns the number of
 // parts (1 = one launch).  g_split_left: largest leftover (in 256^2 tiles) that is split off; 0 disables both plans.
 extern "C" int demo_gemm_set_pp_epilogue(int reg) { g_pp_reg_epi = reg != 0; return 0; }
+static int g_rem160 = 1;
+extern "C" int demo_gemm_set_rem160(int on) { g_rem160 = on != 0; return 0; }
 static int g_split_left = 128;
 static int g_split_eq_max_k = 0;       // OFF by default: -0.12 ms of a 35.7 ms step at 1024, see above
 extern "C" int demo_gemm_set_split(int max_left_tiles) { g_split_left = max_left_tiles; return 0; }
@@ -1464,7 +1503,11 @@ int demo_gemm_bf16_split_plan(const demo_gemm_desc& d, int32_t* rows, int32_t* c
   const int64_t tm1 = full * 256 / ntn;
   if (tm1 < 1 || tm1 * 256 >= d.M) return 1;
   rows[0] = (int32_t)(tm1 * 256); cfg[0] = 2566;
-  rows[1] = (int32_t)(d.M - tm1 * 256); cfg[1] = 1282;
+  rows[1] = (int32_t)(d.M - tm1 * 256);
+  // The remainder on 128^2 tiles at two workgroups per CU keeps ONE K-tile (32 KB) in flight per workgroup and walks K at one exposed load
+  // latency per step (~1.1 us: 55 us for K = 3072).  When it fits one round of 160 x 128 tiles it takes that configuration instead: one
+  // workgroup per CU, three LDS buffers, two K-tiles in flight (g_rem160, demo_gemm_set_rem160).
+  cfg[1] = (g_rem160 && cdiv64(rows[1], 160) * (d.N / 128) <= 256) ? 1603 : 1282;
   return 2;
 }
 // (kept for callers of the round-1 ABI: rows of the first part when the product is split, 0 = one launch)
@@ -1527,9 +1570,9 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
     }
     // Issued back to back on the caller's stream.  Opt-in experiment for plan (a) (demo_gemm_set_split_overlap): the remainder forked onto
     // a side stream, ready at the same moment as the main part; the caller's stream joins both before anything else runs.
-    SideStream* side = (g_split_overlap && nparts == 2 && pcfg[1] == 1282) ? side_stream() : nullptr;
+    SideStream* side = (g_split_overlap && nparts == 2 && pcfg[1] != 2566) ? side_stream() : nullptr;
     if (side && hipEventRecord(side->fork, s) == hipSuccess && hipStreamWaitEvent(side->st, side->fork, 0) == hipSuccess) {
-      int rc = demo_gemm_bf16_launch(part[1], side->st, 1282);
+      int rc = demo_gemm_bf16_launch(part[1], side->st, pcfg[1]);
       const hipError_t e1 = hipEventRecord(side->join, side->st);
       if (rc == 0) rc = demo_gemm_bf16_launch(part[0], s, 2566);
       const hipError_t e2 = hipStreamWaitEvent(s, side->join, 0);
@@ -1587,6 +1630,7 @@ static int demo_gemm_bf16_launch(const demo_gemm_desc& d, hipStream_t s, int cfg
     case 2563: LAUNCH(256, 128, 4, 2, 3); break;
     case 644: LAUNCH(64, 64, 2, 2, 4); break;        // small-M products (eval at small batches): 4x the workgroups, 3 K-tiles in flight
     case 1283: LAUNCH(128, 128, 2, 2, 3); break;
+    case 1603: LAUNCH(160, 128, 2, 2, 3); break;     // row-split remainders that fit one round: one workgroup per CU, two K-tiles in flight
     case 1284: LAUNCH(128, 128, 2, 2, 4); break;
     case 2566:
       p.ntm = (int)cdiv64(d.M, 256);

@@ -92,6 +92,7 @@ int demo_gemm_split_rows(const demo_gemm_desc* d);
  * measured -0.12 ms of a 35.7 ms training step at 1024, i.e. for the K = 768 products of N = 768, and slower on the long-K products). */
 int demo_gemm_split_plan(const demo_gemm_desc* d, int32_t* rows, int32_t* cfg, int32_t max_parts);
 int demo_gemm_set_split_equal(int max_k);
+int demo_gemm_set_rem160(int on);      /* tuning hook: 1 (default) = a row-split remainder that fits one round of 160x128 tiles takes that 3-buffer configuration (cfg 1603), 0 = always 128x128 */
 int demo_gemm_set_pp_min_fill(int pct); /* tuning hook: least fill (%) of the last round of 256 CUs at which short-K products still take the 256x256 kernel (default 70) */
 int demo_gemm_set_pp_epilogue(int reg); /* tuning hook, 256x256 kernel: 1 (default) = epilogue straight from the accumulators, 0 = LDS-staged */
 int demo_gemm_set_split(int max_left_tiles);

@@ -105,7 +105,7 @@ def test_gemm_bf16_mfma(M, N, K):
         assert torch.equal(got.cpu(), a2.bfloat16().float() @ b2.bfloat16().float().t())
 
 
-@pytest.mark.parametrize("reg_epi,tile", [(1, 2566), (0, 2566), (1, 2576), (1, 644)])
+@pytest.mark.parametrize("reg_epi,tile", [(1, 2566), (0, 2566), (1, 2576), (1, 644), (1, 1603)])
 @pytest.mark.parametrize("M,N,K", [(700, 512, 192), (1300, 256, 64), (256, 768, 128), (3 * 256 + 5, 384, 64)])
 def test_gemm_bf16_256_kernel_epilogues(M, N, K, reg_epi, tile):
     """The 256x256 ping-pong kernel forced (the heuristic only takes it on chip-filling shapes), both epilogue forms: the register
@@ -117,7 +117,7 @@ def test_gemm_bf16_256_kernel_epilogues(M, N, K, reg_epi, tile):
     if K % 64 or (tile == 2566 and N % 256):
         pytest.skip("shape outside this tile configuration's contract")
     lib.demo_gemm_set_pp_epilogue(reg_epi)
-    lib.demo_gemm_force_tile(tile)            # 2566: 256x256 ping-pong kernel; 2576: 256x128 twin kernel (two workgroups per CU, BK = 32); 644: 64x64, 4 stages (small M)
+    lib.demo_gemm_force_tile(tile)            # 2566: 256x256 ping-pong kernel; 2576: 256x128 twin kernel (two workgroups per CU, BK = 32); 644: 64x64, 4 stages (small M); 1603: 160x128, 3 stages (row-split remainders)
     try:
         a2 = torch.zeros(M, K)
         a2[:K, :K] = torch.eye(K)
@@ -151,7 +151,7 @@ def test_gemm_bf16_256_kernel_epilogues(M, N, K, reg_epi, tile):
 
 
 @pytest.mark.parametrize("force,dt,stage", [(0, torch.float32, 1), (1282, torch.bfloat16, 1), (2566, torch.bfloat16, 1), (2566, torch.bfloat16, 0),
-                                            (2576, torch.bfloat16, 1), (2562, torch.bfloat16, 1)])
+                                            (2576, torch.bfloat16, 1), (2562, torch.bfloat16, 1), (1603, torch.bfloat16, 1)])
 @pytest.mark.parametrize("kind", [ACT_QUICKGELU, ACT_GELU])
 def test_gemm_saved_activation_derivative_d8(force, dt, stage, kind):
     """pre_out_kind 2 / dtPre DEMO_D8 (demo_hip.h): the forward epilogue saves act'(x) as one byte per element, q = rint((a + 0.13) * 200);
@@ -278,7 +278,7 @@ def test_gemm_bf16_equal_parts_plan():
     rows, cfgs = (C.c_int32 * 4)(), (C.c_int32 * 4)()
     lib.demo_gemm_set_split_equal(1024)                    # (the equal-parts plan is an opt-in hook: off by default)
     assert lib.demo_gemm_split_plan(C.byref(d), rows, cfgs, 4) == 2                                   # long K: main + remainder
-    assert list(rows)[:2] == [170 * 256, 49536 - 170 * 256] and list(cfgs)[:2] == [2566, 1282]
+    assert list(rows)[:2] == [170 * 256, 49536 - 170 * 256] and list(cfgs)[:2] == [2566, 1603]
     d.K = 768                                              # short K: three equal launches
     assert lib.demo_gemm_split_plan(C.byref(d), rows, cfgs, 4) == 3
     assert list(rows)[:3] == [65 * 256, 65 * 256, 49536 - 130 * 256] and list(cfgs)[:3] == [2566] * 3
