@@ -74,8 +74,8 @@ template <> struct io<bf16_t> {
   }
   static __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     uint2 r;
-    r.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-    r.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    r.x = pack_bf16x2(v.x, v.y);
+    r.y = pack_bf16x2(v.z, v.w);
     *reinterpret_cast<uint2*>(p) = r;
   }
 };
@@ -106,16 +106,34 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- activations ---------------------------------------------------------------------------------
+// QuickGELU: x * sigmoid(1.702 x) with sigmoid(1.702 x) = 1 / (1 + 2^(x * QG_K2)), QG_K2 = -1.702 * log2(e): ONE multiply in front of
+// v_exp_f32 (2^x), v_rcp_f32 (1 ulp) for the division.  Every form below -- scalar, and the two-wide forms the GEMM epilogues use
+// (v_pk_mul/add/fma_f32: two floats per lane and issue slot) -- evaluates the same expression in the same order, so a value does not
+// depend on which kernel or tile configuration produced it.
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define DEMO_QG_K2 (-2.45546696f)
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }          // v_pk_fma_f32
+__device__ __forceinline__ v2f pk_fma(v2f a, float b, float c) { return __builtin_elementwise_fma(a, (v2f){b, b}, (v2f){c, c}); }
+__device__ __forceinline__ v2f pk_fma(v2f a, float b, v2f c) { return __builtin_elementwise_fma(a, (v2f){b, b}, c); }
+__device__ __forceinline__ float qg_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * DEMO_QG_K2)); }
+__device__ __forceinline__ v2f qg_sigmoid2(v2f x) {
+  const v2f z = x * DEMO_QG_K2;
+  v2f e;
+  e.x = __builtin_amdgcn_exp2f(z.x); e.y = __builtin_amdgcn_exp2f(z.y);
+  const v2f den = e + 1.0f;
+  v2f s;
+  s.x = __builtin_amdgcn_rcpf(den.x); s.y = __builtin_amdgcn_rcpf(den.y);
+  return s;
+}
 __device__ __forceinline__ float act_apply(float x, int act) {
-  // (v_rcp_f32 is accurate to 1 ulp; a true division is ~10 more instructions per element of the GEMM epilogue)
-  if (act == DEMO_ACT_QUICKGELU) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+  if (act == DEMO_ACT_QUICKGELU) return x * qg_sigmoid(x);
   if (act == DEMO_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
   return x;
 }
 __device__ __forceinline__ float act_grad(float x, int act) {
   if (act == DEMO_ACT_QUICKGELU) {
-    float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
-    return s * (1.0f + 1.702f * x * (1.0f - s));
+    const float s = qg_sigmoid(x);
+    return fmaf(1.702f * (x * s), 1.0f - s, s);          // s (1 + 1.702 x (1 - s))
   }
   if (act == DEMO_ACT_GELU) {
     float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
@@ -128,7 +146,7 @@ __device__ __forceinline__ float act_grad(float x, int act) {
 // activation and its derivative from ONE evaluation of the shared transcendental part (forward epilogues that save act'(x))
 __device__ __forceinline__ float act_both(float x, int act, float& d) {
   if (act == DEMO_ACT_QUICKGELU) {
-    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+    const float s = qg_sigmoid(x);
     const float u = x * s;
     d = fmaf(1.702f * u, 1.0f - s, s);          // s (1 + 1.702 x (1 - s))
     return u;
@@ -141,23 +159,57 @@ __device__ __forceinline__ float act_both(float x, int act, float& d) {
   d = 1.0f;
   return x;
 }
+// two-wide forms (erf-GELU has no packed transcendental path: per component)
+__device__ __forceinline__ v2f act_apply2(v2f x, int act) {
+  if (act == DEMO_ACT_QUICKGELU) return x * qg_sigmoid2(x);
+  if (act == DEMO_ACT_NONE) return x;
+  return (v2f){act_apply(x.x, act), act_apply(x.y, act)};
+}
+__device__ __forceinline__ v2f act_grad2(v2f x, int act) {
+  if (act == DEMO_ACT_QUICKGELU) {
+    const v2f s = qg_sigmoid2(x);
+    return pk_fma(1.702f * (x * s), 1.0f - s, s);
+  }
+  if (act == DEMO_ACT_SAVED) return x;
+  return (v2f){act_grad(x.x, act), act_grad(x.y, act)};
+}
+__device__ __forceinline__ v2f act_both2(v2f x, int act, v2f& d) {
+  if (act == DEMO_ACT_QUICKGELU) {
+    const v2f s = qg_sigmoid2(x);
+    const v2f u = x * s;
+    d = pk_fma(1.702f * u, 1.0f - s, s);
+    return u;
+  }
+  float d0, d1;
+  const float r0 = act_both(x.x, act, d0), r1 = act_both(x.y, act, d1);
+  d = (v2f){d0, d1};
+  return (v2f){r0, r1};
+}
 
 // ---- DEMO_D8: 8-bit code of a saved activation derivative (demo_hip.h) ----------------------------------------------------------
 // q = rint((a + 0.13) * 200): the rounding is done explicitly (v_rndne_f32), so the byte conversion sees an integer and its own
 // rounding mode does not matter; v_cvt_pk_u8_f32 saturates to [0, 255] and inserts the byte into a dword.
-__device__ __forceinline__ uint32_t d8_pack4(float a0, float a1, float a2, float a3) {
+__device__ __forceinline__ uint32_t d8_pack4(v2f a, v2f b) {
+  const v2f qa = pk_fma(a, 200.0f, 26.0f), qb = pk_fma(b, 200.0f, 26.0f);
   uint32_t w = 0;
-  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(a0, 200.0f, 26.0f)), 0, w);
-  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(a1, 200.0f, 26.0f)), 1, w);
-  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(a2, 200.0f, 26.0f)), 2, w);
-  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(a3, 200.0f, 26.0f)), 3, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(qa.x), 0, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(qa.y), 1, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(qb.x), 2, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(qb.y), 3, w);
   return w;
 }
+__device__ __forceinline__ uint32_t d8_pack4(float a0, float a1, float a2, float a3) { return d8_pack4((v2f){a0, a1}, (v2f){a2, a3}); }
 __device__ __forceinline__ uint8_t d8_encode(float a) { return (uint8_t)(d8_pack4(a, 0.f, 0.f, 0.f) & 0xffu); }
 __device__ __forceinline__ float d8_decode(uint32_t q) { return fmaf((float)q, 0.005f, -0.13f); }
-// the four bytes of a dword (v_cvt_f32_ubyte0..3 + one fma each)
+// the four bytes of a dword (v_cvt_f32_ubyte0..3, then two v_pk_fma_f32)
+__device__ __forceinline__ void d8_unpack4(uint32_t w, v2f& lo, v2f& hi) {
+  lo = pk_fma((v2f){(float)(w & 0xffu), (float)((w >> 8) & 0xffu)}, 0.005f, -0.13f);
+  hi = pk_fma((v2f){(float)((w >> 16) & 0xffu), (float)(w >> 24)}, 0.005f, -0.13f);
+}
 __device__ __forceinline__ float4 d8_unpack4(uint32_t w) {
-  return make_float4(d8_decode(w & 0xffu), d8_decode((w >> 8) & 0xffu), d8_decode((w >> 16) & 0xffu), d8_decode(w >> 24));
+  v2f lo, hi;
+  d8_unpack4(w, lo, hi);
+  return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
 
 // ---- attention kernels: 16-B output rows ----------------------------------------------------------------------------------------

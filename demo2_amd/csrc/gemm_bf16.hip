@@ -157,14 +157,12 @@ __device__ __forceinline__ void bf16x8_to_f32(const uint4 r, float4& lo, float4&
   hi = make_float4(__uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u), __uint_as_float(r.w << 16),
                    __uint_as_float(r.w & 0xffff0000u));
 }
-__device__ __forceinline__ uint4 f32x8_to_bf16(const float (&v)[8]) {
-  uint4 r;
-  r.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-  r.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-  r.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-  r.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-  return r;
+// (one v_cvt_pk_bf16_f32 per PAIR: the `f2bf(a) | f2bf(b) << 16` spelling compiled to two conversions, a shift and an or)
+__device__ __forceinline__ uint4 f32x8_to_bf16(const v2f (&v)[4]) {
+  return make_uint4(pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[1].x, v[1].y), pack_bf16x2(v[2].x, v[2].y), pack_bf16x2(v[3].x, v[3].y));
 }
+__device__ __forceinline__ v2f lo2(const float4 a) { return (v2f){a.x, a.y}; }
+__device__ __forceinline__ v2f hi2(const float4 a) { return (v2f){a.z, a.w}; }
 // ACT / GK: activation and activation-gradient kinds as COMPILE-TIME constants (-1 = read them from p at run time).  With both
 // as run-time switches every row instance carried QuickGELU and erf-GELU, forward and derivative: 157 KB of code for the
 // 256^2 kernel against a 64-KB instruction cache, and its epilogue ran at instruction-fetch speed.
@@ -211,66 +209,61 @@ __device__ __forceinline__ void st8(void* base, int64_t off, const uint2 v) {
   *reinterpret_cast<uint2*>(reinterpret_cast<char*>(base) + off) = v;
 #endif
 }
-__device__ __forceinline__ uint2 d8_pack8(const float (&s)[8]) { return make_uint2(d8_pack4(s[0], s[1], s[2], s[3]), d8_pack4(s[4], s[5], s[6], s[7])); }
+__device__ __forceinline__ uint2 d8_pack8(const v2f (&s)[4]) { return make_uint2(d8_pack4(s[0], s[1]), d8_pack4(s[2], s[3])); }
 __device__ __forceinline__ void d8_unpack8(const uint2 r, float4& lo, float4& hi) { lo = d8_unpack4(r.x); hi = d8_unpack4(r.y); }
 __device__ __forceinline__ u32x4 as_u32x4(const uint4 r) { return (u32x4){r.x, r.y, r.z, r.w}; }
 __device__ __forceinline__ u32x4 as_u32x4(float a, float b, float c, float d) {
   return (u32x4){__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
 }
 
-// v: in = alpha * accumulator, out = the 8 values of C; s: the 8 values of the second output (pre-activation or act'), valid iff p.pre_out
-template <int ACT, int GK>
-__device__ __forceinline__ void epi8_compute(const FArgs& p, const float4 bz0, const float4 bz1, const EpiOps& x, float (&v)[8], float (&s)[8]) {
+// v: in = alpha * accumulator (+ bias when ADD_BIAS is false: the caller folded it into one fma), out = the 8 values of C as four PAIRS;
+// s: the 8 values of the second output (pre-activation or act'), valid iff p.pre_out.  Everything is two-wide (v_pk_*_f32: two floats per
+// lane and issue slot): with all eight waves of a tile in their epilogue at once and no MFMA to hide behind, the epilogue is VALU time.
+template <int ACT, int GK, bool ADD_BIAS = true>
+__device__ __forceinline__ void epi8_compute(const FArgs& p, const float4 bz0, const float4 bz1, const EpiOps& x, v2f (&v)[4], v2f (&s)[4]) {
   const int act = ACT >= 0 ? ACT : p.act;
   const int gk = GK >= 0 ? GK : p.act_grad_kind;
   const bool has_pre = GK >= 0 ? GK != DEMO_ACT_NONE : p.pre != nullptr;
-  v[0] += bz0.x; v[1] += bz0.y; v[2] += bz0.z; v[3] += bz0.w;
-  v[4] += bz1.x; v[5] += bz1.y; v[6] += bz1.z; v[7] += bz1.w;
+  if (ADD_BIAS) { v[0] += lo2(bz0); v[1] += hi2(bz0); v[2] += lo2(bz1); v[3] += hi2(bz1); }
   const bool save_deriv = p.pre_out && p.pre_out_kind >= 1;
   if (p.pre_out) {
     if (save_deriv) {                                      // activation and its derivative from one exp / rcp (or erf) per element
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = act_both(v[e], act, s[e]);
+      for (int e = 0; e < 4; ++e) v[e] = act_both2(v[e], act, s[e]);
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s[e] = v[e];
+      for (int e = 0; e < 4; ++e) s[e] = v[e];
     }
   }
   if (act != DEMO_ACT_NONE && !save_deriv) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e], act);
+    for (int e = 0; e < 4; ++e) v[e] = act_apply2(v[e], act);
   }
   if (has_pre) {
-    const float pr[8] = {x.pre0.x, x.pre0.y, x.pre0.z, x.pre0.w, x.pre1.x, x.pre1.y, x.pre1.z, x.pre1.w};
+    const v2f pr[4] = {lo2(x.pre0), hi2(x.pre0), lo2(x.pre1), hi2(x.pre1)};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= act_grad(pr[e], gk);
+    for (int e = 0; e < 4; ++e) v[e] *= act_grad2(pr[e], gk);
   }
-  if (p.residual) {
-    v[0] += x.res0.x; v[1] += x.res0.y; v[2] += x.res0.z; v[3] += x.res0.w;
-    v[4] += x.res1.x; v[5] += x.res1.y; v[6] += x.res1.z; v[7] += x.res1.w;
-  }
-  if (p.dtC == DEMO_F32 && p.accumulate) {
-    v[0] += x.old0.x; v[1] += x.old0.y; v[2] += x.old0.z; v[3] += x.old0.w;
-    v[4] += x.old1.x; v[5] += x.old1.y; v[6] += x.old1.z; v[7] += x.old1.w;
-  }
+  if (p.residual) { v[0] += lo2(x.res0); v[1] += hi2(x.res0); v[2] += lo2(x.res1); v[3] += hi2(x.res1); }
+  if (p.dtC == DEMO_F32 && p.accumulate) { v[0] += lo2(x.old0); v[1] += hi2(x.old0); v[2] += lo2(x.old1); v[3] += hi2(x.old1); }
 }
-template <int ACT, int GK>
-__device__ __forceinline__ void epi8_finish(const FArgs& p, const float4 bz0, const float4 bz1, const EpiOps& x, int64_t ci, float (&v)[8]) {
-  float s[8];
-  epi8_compute<ACT, GK>(p, bz0, bz1, x, v, s);
+template <int ACT, int GK, bool ADD_BIAS = true>
+__device__ __forceinline__ void epi8_finish(const FArgs& p, const float4 bz0, const float4 bz1, const EpiOps& x, int64_t ci, v2f (&v)[4]) {
+  v2f s[4];
+  epi8_compute<ACT, GK, ADD_BIAS>(p, bz0, bz1, x, v, s);
   if (p.pre_out) {
     if (p.pre_out_kind == 2) {
       st8(p.pre_out, ci, d8_pack8(s));
     } else if (p.dtC == DEMO_F32) {
-      st16(p.pre_out, ci * 4, as_u32x4(s[0], s[1], s[2], s[3]));
-      st16(p.pre_out, ci * 4 + 16, as_u32x4(s[4], s[5], s[6], s[7]));
+      st16(p.pre_out, ci * 4, as_u32x4(s[0].x, s[0].y, s[1].x, s[1].y));
+      st16(p.pre_out, ci * 4 + 16, as_u32x4(s[2].x, s[2].y, s[3].x, s[3].y));
     } else {
       st16(p.pre_out, ci * 2, as_u32x4(f32x8_to_bf16(s)));
     }
   }
   if (p.dtC == DEMO_F32) {
-    st16(p.C, ci * 4, as_u32x4(v[0], v[1], v[2], v[3]));
-    st16(p.C, ci * 4 + 16, as_u32x4(v[4], v[5], v[6], v[7]));
+    st16(p.C, ci * 4, as_u32x4(v[0].x, v[0].y, v[1].x, v[1].y));
+    st16(p.C, ci * 4 + 16, as_u32x4(v[2].x, v[2].y, v[3].x, v[3].y));
   } else {
     st16(p.C, ci * 2, as_u32x4(f32x8_to_bf16(v)));
   }
@@ -363,7 +356,7 @@ __device__ __forceinline__ void epi_rows_k(const FArgs& p, const float* __restri
       if ((g0 + u) > rows_ok) continue;
       const float4 lo = *reinterpret_cast<const float4*>(ctl + (g0 + u) * (RSTEP * BN_));
       const float4 hi = *reinterpret_cast<const float4*>(cth + (g0 + u) * (RSTEP * BN_));
-      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      v2f v[4] = {lo2(lo), hi2(lo), lo2(hi), hi2(hi)};
       epi8_finish<ACT, GK>(p, bz0, bz1, x[u], ci[u], v);
     }
   }
@@ -548,29 +541,31 @@ __device__ __forceinline__ void pp_epi_k(const FArgs& p, const f32x4 (&acc)[8][4
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const f32x4 a = acc[i0 + u][2 * h], b = acc[i0 + u][2 * h + 1];
-        float v[8] = {a[0] * p.alpha, a[1] * p.alpha, a[2] * p.alpha, a[3] * p.alpha, b[0] * p.alpha, b[1] * p.alpha, b[2] * p.alpha, b[3] * p.alpha};
+        // alpha * accumulator + bias, one v_pk_fma_f32 per pair (bias zero when it was the accumulators' initial value)
+        v2f v[4] = {pk_fma((v2f){a[0], a[1]}, p.alpha, lo2(bz[h][0])), pk_fma((v2f){a[2], a[3]}, p.alpha, hi2(bz[h][0])),
+                    pk_fma((v2f){b[0], b[1]}, p.alpha, lo2(bz[h][1])), pk_fma((v2f){b[2], b[3]}, p.alpha, hi2(bz[h][1]))};
         if constexpr (SINK == 0) {
-          epi8_finish<ACT, GK>(p, bz[h][0], bz[h][1], x[u][h], ci[u][h], v);
+          epi8_finish<ACT, GK, false>(p, bz[h][0], bz[h][1], x[u][h], ci[u][h], v);
         } else {
           const int ch = ((ncol - n0) >> 3) + h * 4;
           if constexpr (SINK == 3) {                   // activation + DEMO_D8 code of its derivative, each code packed as soon as it exists
             static_assert(ACT > 0 && LOADS == 0, "SINK 3 is the fc1 forward: bias, activation, two outputs");
-            const float bb[8] = {bz[h][0].x, bz[h][0].y, bz[h][0].z, bz[h][0].w, bz[h][1].x, bz[h][1].y, bz[h][1].z, bz[h][1].w};
-            uint32_t w[2] = {0u, 0u};
+            uint32_t w[2];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              float dv;
-              v[e] = act_both(v[e] + bb[e], ACT, dv);
-              w[e >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(dv, 200.0f, 26.0f)), e & 3, w[e >> 2]);
-              if (e == 3) __builtin_amdgcn_sched_barrier(0);     // four elements' transcendental temporaries at a time: the kernel sits at 256 VGPRs
+            for (int e = 0; e < 2; ++e) {
+              v2f d0, d1;
+              v[2 * e] = act_both2(v[2 * e], ACT, d0);
+              v[2 * e + 1] = act_both2(v[2 * e + 1], ACT, d1);
+              w[e] = d8_pack4(d0, d1);
+              if (e == 0) __builtin_amdgcn_sched_barrier(0);     // four elements' transcendental temporaries at a time: the kernel sits at 256 VGPRs
             }
             const int hr = (mrow - m0) - ((mrow - m0) >> 7) * 64 + ((i0 + u) & 3) * 16;
             *reinterpret_cast<uint2*>(lds + 65536 + pp_d8_slot(hr, ch)) = make_uint2(w[0], w[1]);
             *reinterpret_cast<u32x4*>(lds + pp_tile_slot(hr, ch)) = as_u32x4(f32x8_to_bf16(v));
             continue;
           }
-          float sv[8];
-          epi8_compute<ACT, GK>(p, bz[h][0], bz[h][1], x[u][h], v, sv);
+          v2f sv[4];
+          epi8_compute<ACT, GK, false>(p, bz[h][0], bz[h][1], x[u][h], v, sv);
           if constexpr (SINK == 1) {
             *reinterpret_cast<u32x4*>(lds + pp_tile_slot(mrow - m0 + (i0 + u) * 16, ch)) = as_u32x4(f32x8_to_bf16(v));
           } else {                                   // two 128-row half images (C, second output): image row = wr * 64 + (i & 3) * 16 + frow

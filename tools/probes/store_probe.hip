@@ -12,7 +12,8 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 //            128-B line, rows N*2 bytes apart;  1: whole 512-B tile rows (32 lanes per row, 2 rows per instruction);
 //            2: the tile as ONE contiguous 128-KB block (blocked output layout)
 template <int PATTERN>
-__global__ __launch_bounds__(512, 1) void writer(char* __restrict__ C, int N, int ntn, int keep_lds) {
+__global__ __launch_bounds__(512, 1) void writer(char* __restrict__ C, int N, int ntn, int keep_lds, int xcd_mask = 0xff) {
+  if (!((xcd_mask >> (blockIdx.x & 7)) & 1)) return;          // (round 3) only the workgroups dealt to the XCDs of the mask store
   extern __shared__ char sm[];
   if (keep_lds == 12345) sm[threadIdx.x] = 1;                // keep the 160-KB allocation: one workgroup per CU
   const int tile = blockIdx.x, tm = tile / ntn, tn = tile % ntn;
@@ -61,12 +62,33 @@ template <int PATTERN> float run(char* C, int N, int ntn, int wgs, int reps) {
   hipEventElapsedTime(&ms, e0, e1);
   return ms * 1e3f / reps;
 }
+// (round 3) is the ~6 TB/s store limit chip-wide or per XCD?  256 workgroups launched, only those of 1 / 2 / 4 / 8 XCDs store.
+static float run_mask(char* C, int N, int ntn, int mask, int reps) {
+  hipFuncSetAttribute((const void*)writer<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(writer<1>, dim3(256), dim3(512), 160 * 1024, 0, C, N, ntn, 0, mask);
+  hipEventRecord(e0);
+  for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(writer<1>, dim3(256), dim3(512), 160 * 1024, 0, C, N, ntn, 0, mask);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms * 1e3f / reps;
+}
+
 int main() {
   const int N = 3072, ntn = N / 256, M = 49536;
   char* C;
   hipMalloc(&C, (size_t)M * N * 2);
   const char* names[4] = {"16 rows x 64 B per instruction (register epilogue)", "2 rows x 512 B per instruction", "contiguous 128-KB block",
                           "8 rows x 128 B per instruction (lane-pair exchange)"};
+  for (int mask : {0x01, 0x03, 0x0f, 0xff}) {
+    int n = 0;
+    for (int b = 0; b < 8; ++b) n += (mask >> b) & 1;
+    const float t = run_mask(C, N, ntn, mask, 20);
+    printf("256 workgroups launched, XCD mask 0x%02x (%d workgroups store, 32 per XCD): %7.2f us per launch  %6.0f GB/s\n", mask, n * 32, t, n * 32 * 131072.0 / t / 1e3);
+  }
   for (int wgs : {1, 32, 64, 128, 256, 512, 1024, 2328}) {
     const float t[4] = {run<0>(C, N, ntn, wgs, 20), run<1>(C, N, ntn, wgs, 20), run<2>(C, N, ntn, wgs, 20), run<3>(C, N, ntn, wgs, 20)};
     for (int p = 0; p < 4; ++p) {
