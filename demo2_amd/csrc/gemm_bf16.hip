@@ -219,14 +219,19 @@ __device__ __forceinline__ u32x4 as_u32x4(float a, float b, float c, float d) {
 // v: in = alpha * accumulator (+ bias when ADD_BIAS is false: the caller folded it into one fma), out = the 8 values of C as four PAIRS;
 // s: the 8 values of the second output (pre-activation or act'), valid iff p.pre_out.  Everything is two-wide (v_pk_*_f32: two floats per
 // lane and issue slot): with all eight waves of a tile in their epilogue at once and no MFMA to hide behind, the epilogue is VALU time.
-template <int ACT, int GK, bool ADD_BIAS = true>
+// LOADS / SECOND: what the caller knows at compile time about the optional operands (LOADS: pp_epi_k's mask, -1 = look at p) and about a
+// second output (0 none, 1 yes, -1 = look at p): a run-time `if (p.residual) v += r` compiles to the add AND a v_cndmask per element.
+template <int ACT, int GK, bool ADD_BIAS = true, int LOADS = -1, int SECOND = -1>
 __device__ __forceinline__ void epi8_compute(const FArgs& p, const float4 bz0, const float4 bz1, const EpiOps& x, v2f (&v)[4], v2f (&s)[4]) {
   const int act = ACT >= 0 ? ACT : p.act;
   const int gk = GK >= 0 ? GK : p.act_grad_kind;
-  const bool has_pre = GK >= 0 ? GK != DEMO_ACT_NONE : p.pre != nullptr;
+  const bool has_pre = LOADS >= 0 ? (LOADS & 2) != 0 : (GK >= 0 ? GK != DEMO_ACT_NONE : p.pre != nullptr);
+  const bool has_res = LOADS >= 0 ? (LOADS & 1) != 0 : p.residual != nullptr;
+  const bool has_old = LOADS >= 0 ? false : (p.dtC == DEMO_F32 && p.accumulate);
+  const bool second = SECOND >= 0 ? SECOND != 0 : p.pre_out != nullptr;
   if (ADD_BIAS) { v[0] += lo2(bz0); v[1] += hi2(bz0); v[2] += lo2(bz1); v[3] += hi2(bz1); }
-  const bool save_deriv = p.pre_out && p.pre_out_kind >= 1;
-  if (p.pre_out) {
+  const bool save_deriv = second && p.pre_out_kind >= 1;
+  if (second) {
     if (save_deriv) {                                      // activation and its derivative from one exp / rcp (or erf) per element
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = act_both2(v[e], act, s[e]);
@@ -244,13 +249,13 @@ __device__ __forceinline__ void epi8_compute(const FArgs& p, const float4 bz0, c
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] *= act_grad2(pr[e], gk);
   }
-  if (p.residual) { v[0] += lo2(x.res0); v[1] += hi2(x.res0); v[2] += lo2(x.res1); v[3] += hi2(x.res1); }
-  if (p.dtC == DEMO_F32 && p.accumulate) { v[0] += lo2(x.old0); v[1] += hi2(x.old0); v[2] += lo2(x.old1); v[3] += hi2(x.old1); }
+  if (has_res) { v[0] += lo2(x.res0); v[1] += hi2(x.res0); v[2] += lo2(x.res1); v[3] += hi2(x.res1); }
+  if (has_old) { v[0] += lo2(x.old0); v[1] += hi2(x.old0); v[2] += lo2(x.old1); v[3] += hi2(x.old1); }
 }
-template <int ACT, int GK, bool ADD_BIAS = true>
+template <int ACT, int GK, bool ADD_BIAS = true, int LOADS = -1>
 __device__ __forceinline__ void epi8_finish(const FArgs& p, const float4 bz0, const float4 bz1, const EpiOps& x, int64_t ci, v2f (&v)[4]) {
   v2f s[4];
-  epi8_compute<ACT, GK, ADD_BIAS>(p, bz0, bz1, x, v, s);
+  epi8_compute<ACT, GK, ADD_BIAS, LOADS>(p, bz0, bz1, x, v, s);
   if (p.pre_out) {
     if (p.pre_out_kind == 2) {
       st8(p.pre_out, ci, d8_pack8(s));
@@ -403,27 +408,40 @@ __device__ __forceinline__ void pp_drain_half_d8(const FArgs& p, void* out, cons
                                                  int lane) {
   u32x4 r[4];
   const int rsub = lane >> 4, s16 = lane & 15;
+  // (hr & 15 = it * 4 + rsub: the slot is a per-lane base XOR a constant, the row a constant offset -- one VALU op per read)
+  const unsigned rd0 = (unsigned)((wave * 16 + rsub) * 256 + ((s16 ^ rsub) << 4));
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int hr = wave * 16 + it * 4 + rsub;
-    r[it] = *reinterpret_cast<const u32x4*>(img + hr * 256 + (((s16 ^ hr) & 15) << 4));
-  }
+  for (int it = 0; it < 4; ++it) r[it] = *reinterpret_cast<const u32x4*>(img + (rd0 ^ (unsigned)(it * 64)) + it * 1024);
+  // image row hr = wave * 16 + it * 4 + rsub is tile row (hr >> 6) * 128 + half * 64 + (hr & 63): linear in `it`, so the row offset advances
+  // by a constant (a 64-bit multiply per row cost more VALU time than the epilogue's arithmetic)
+  const int mf = m0 + (wave >> 2) * 128 + half * 64 + (wave & 3) * 16 + rsub;
+  const int64_t off0 = coff + (int64_t)mf * p.ldc + n0 + s16 * 16, step = 4 * p.ldc;        // (byte offsets: one byte per element)
+  if (m0 + 256 <= p.M) {                            // whole tile inside the matrix (all but the last row panel): no per-row guard
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int hr = wave * 16 + it * 4 + rsub;
-    const int m = m0 + (hr >> 6) * 128 + half * 64 + (hr & 63);
-    if (m < p.M) st16(out, coff + (int64_t)m * p.ldc + n0 + s16 * 16, r[it]);        // (byte offsets: one byte per element)
+    for (int it = 0; it < 4; ++it) st16(out, off0 + it * step, r[it]);
+  } else {
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      if (mf + it * 4 < p.M) st16(out, off0 + it * step, r[it]);
   }
 }
 __device__ __forceinline__ void pp_drain(const FArgs& p, void* out, const char* lds, int m0, int n0, int64_t coff, int wave, int lane) {
   u32x4 r[16];
   const int rsub = lane >> 5, chunk = lane & 31;
+  // pp_tile_slot(wave * 32 + it * 2 + rsub, chunk): row & 31 = it * 2 + rsub, so the slot is a per-lane base XOR (it * 2) << 4 and the row a
+  // constant offset (the spelled-out form cost five VALU ops per read)
+  const unsigned rd0 = (unsigned)((wave * 32 + rsub) * 512 + ((chunk ^ rsub) << 4));
 #pragma unroll
-  for (int it = 0; it < 16; ++it) r[it] = *reinterpret_cast<const u32x4*>(lds + pp_tile_slot(wave * 32 + it * 2 + rsub, chunk));
+  for (int it = 0; it < 16; ++it) r[it] = *reinterpret_cast<const u32x4*>(lds + (rd0 ^ (unsigned)(it * 32)) + it * 1024);
+  const int mf = m0 + wave * 32 + rsub;
+  const int64_t off0 = (coff + (int64_t)mf * p.ldc + n0 + chunk * 8) * 2, step = 4 * p.ldc;       // two rows on, in bytes
+  if (m0 + 256 <= p.M) {
 #pragma unroll
-  for (int it = 0; it < 16; ++it) {
-    const int m = m0 + wave * 32 + it * 2 + rsub;
-    if (m < p.M) st16(out, (coff + (int64_t)m * p.ldc + n0 + chunk * 8) * 2, r[it]);
+    for (int it = 0; it < 16; ++it) st16(out, off0 + it * step, r[it]);
+  } else {
+#pragma unroll
+    for (int it = 0; it < 16; ++it)
+      if (mf + it * 2 < p.M) st16(out, off0 + it * step, r[it]);
   }
 }
 // half images of SINK 2: 128 image rows = the 64-row half `half` of both wave rows; 16 image rows per wave
@@ -431,13 +449,19 @@ __device__ __forceinline__ void pp_drain_half(const FArgs& p, void* out, const c
                                               int lane) {
   u32x4 r[8];
   const int rsub = lane >> 5, chunk = lane & 31;
+  // image row wave * 16 + it * 2 + rsub: row & 31 = (wave & 1) * 16 + it * 2 + rsub
+  const unsigned rd0 = (unsigned)((wave * 16 + rsub) * 512 + ((chunk ^ (rsub + (wave & 1) * 16)) << 4));
 #pragma unroll
-  for (int it = 0; it < 8; ++it) r[it] = *reinterpret_cast<const u32x4*>(img + pp_tile_slot(wave * 16 + it * 2 + rsub, chunk));
+  for (int it = 0; it < 8; ++it) r[it] = *reinterpret_cast<const u32x4*>(img + (rd0 ^ (unsigned)(it * 32)) + it * 1024);
+  const int mf = m0 + (wave >> 2) * 128 + half * 64 + (wave & 3) * 16 + rsub;          // image row wave * 16 + it * 2 + rsub, as above
+  const int64_t off0 = (coff + (int64_t)mf * p.ldc + n0 + chunk * 8) * 2, step = 4 * p.ldc;
+  if (m0 + 256 <= p.M) {
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int hr = wave * 16 + it * 2 + rsub;
-    const int m = m0 + (hr >> 6) * 128 + half * 64 + (hr & 63);
-    if (m < p.M) st16(out, (coff + (int64_t)m * p.ldc + n0 + chunk * 8) * 2, r[it]);
+    for (int it = 0; it < 8; ++it) st16(out, off0 + it * step, r[it]);
+  } else {
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+      if (mf + it * 2 < p.M) st16(out, off0 + it * step, r[it]);
   }
 }
 template <int G, int ACT, int GK, int LOADS, int SINK = 0>
@@ -458,6 +482,16 @@ __device__ __forceinline__ void pp_epi_k(const FArgs& p, const f32x4 (&acc)[8][4
       bz[h][1] = *reinterpret_cast<const float4*>(bias + ncol + h * 32 + 4);
     }
   }
+  // LDS image slots (SINK >= 1): the lane's tile row is r0 + i * 16 with r0 = wr * 128 + frow (frow < 16) and its 8-column chunk c0 | h << 2 with
+  // c0 = wc * 8 + g4 (g4 < 4), so pp_tile_slot / pp_d8_slot reduce to a per-lane base XOR a compile-time constant plus a constant row offset:
+  // one VALU op per write (the spelled-out forms re-derive row & 31 and the XOR every time)
+  const int r0 = mrow - m0, c0 = (ncol - n0) >> 3;
+  const unsigned wbase_full = (unsigned)(r0 * 512 + ((c0 ^ (r0 & 15)) << 4));                                  // SINK 1: 256-row image
+  const int hr0 = (r0 & 15) + (r0 >> 7) * 64;                                                                  // SINK 2 / 3: image row of row tile 0 / 4
+  const unsigned wbase_half = (unsigned)(hr0 * 512 + ((c0 ^ (r0 & 15)) << 4));
+  const unsigned wbase_d8 = (unsigned)(hr0 * 256 + ((((c0 >> 1) ^ r0) & 15) << 4) + ((c0 & 1) << 3));
+  // a lane's rows are 16 apart: the element offset of row tile i is rb_first + i * 16 ldc (one 64-bit multiply per lane, not per row)
+  const int64_t rb_first = coff + (int64_t)mrow * p.ldc + ncol, rb_last = coff + (int64_t)(p.M - 1) * p.ldc + ncol, step16 = 16 * p.ldc;
 #pragma unroll
   for (int i0 = 0; i0 < 8; i0 += G) {
     EpiOps x[G][2];
@@ -467,7 +501,7 @@ __device__ __forceinline__ void pp_epi_k(const FArgs& p, const f32x4 (&acc)[8][4
     for (int u = 0; u < G; ++u) {
       const int m = mrow + (i0 + u) * 16;
       ok[u] = m < p.M;
-      const int64_t rb = coff + (int64_t)(ok[u] ? m : p.M - 1) * p.ldc + ncol;     // clamped for the loads; stores are guarded
+      const int64_t rb = ok[u] ? rb_first + (i0 + u) * step16 : rb_last;          // clamped for the loads; stores are guarded
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         ci[u][h] = rb + h * 32;
@@ -545,9 +579,8 @@ __device__ __forceinline__ void pp_epi_k(const FArgs& p, const f32x4 (&acc)[8][4
         v2f v[4] = {pk_fma((v2f){a[0], a[1]}, p.alpha, lo2(bz[h][0])), pk_fma((v2f){a[2], a[3]}, p.alpha, hi2(bz[h][0])),
                     pk_fma((v2f){b[0], b[1]}, p.alpha, lo2(bz[h][1])), pk_fma((v2f){b[2], b[3]}, p.alpha, hi2(bz[h][1]))};
         if constexpr (SINK == 0) {
-          epi8_finish<ACT, GK, false>(p, bz[h][0], bz[h][1], x[u][h], ci[u][h], v);
+          epi8_finish<ACT, GK, false, LOADS>(p, bz[h][0], bz[h][1], x[u][h], ci[u][h], v);
         } else {
-          const int ch = ((ncol - n0) >> 3) + h * 4;
           if constexpr (SINK == 3) {                   // activation + DEMO_D8 code of its derivative, each code packed as soon as it exists
             static_assert(ACT > 0 && LOADS == 0, "SINK 3 is the fc1 forward: bias, activation, two outputs");
             uint32_t w[2];
@@ -559,19 +592,21 @@ __device__ __forceinline__ void pp_epi_k(const FArgs& p, const f32x4 (&acc)[8][4
               w[e] = d8_pack4(d0, d1);
               if (e == 0) __builtin_amdgcn_sched_barrier(0);     // four elements' transcendental temporaries at a time: the kernel sits at 256 VGPRs
             }
-            const int hr = (mrow - m0) - ((mrow - m0) >> 7) * 64 + ((i0 + u) & 3) * 16;
-            *reinterpret_cast<uint2*>(lds + 65536 + pp_d8_slot(hr, ch)) = make_uint2(w[0], w[1]);
-            *reinterpret_cast<u32x4*>(lds + pp_tile_slot(hr, ch)) = as_u32x4(f32x8_to_bf16(v));
+            const int iq = (i0 + u) & 3;
+            *reinterpret_cast<uint2*>(lds + 65536 + (wbase_d8 ^ (unsigned)(h << 5)) + iq * 4096) = make_uint2(w[0], w[1]);
+            *reinterpret_cast<u32x4*>(lds + (wbase_half ^ (unsigned)((h << 6) ^ ((iq & 1) << 8))) + iq * 8192) = as_u32x4(f32x8_to_bf16(v));
             continue;
           }
           v2f sv[4];
-          epi8_compute<ACT, GK, false>(p, bz[h][0], bz[h][1], x[u][h], v, sv);
+          epi8_compute<ACT, GK, false, LOADS, SINK == 1 ? 0 : 1>(p, bz[h][0], bz[h][1], x[u][h], v, sv);
           if constexpr (SINK == 1) {
-            *reinterpret_cast<u32x4*>(lds + pp_tile_slot(mrow - m0 + (i0 + u) * 16, ch)) = as_u32x4(f32x8_to_bf16(v));
+            const int i = i0 + u;
+            *reinterpret_cast<u32x4*>(lds + (wbase_full ^ (unsigned)((h << 6) ^ ((i & 1) << 8))) + i * 8192) = as_u32x4(f32x8_to_bf16(v));
           } else {                                   // two 128-row half images (C, second output): image row = wr * 64 + (i & 3) * 16 + frow
-            const int hr = (mrow - m0) - ((mrow - m0) >> 7) * 64 + ((i0 + u) & 3) * 16;
-            *reinterpret_cast<u32x4*>(lds + pp_tile_slot(hr, ch)) = as_u32x4(f32x8_to_bf16(v));
-            *reinterpret_cast<u32x4*>(lds + 65536 + pp_tile_slot(hr, ch)) = as_u32x4(f32x8_to_bf16(sv));
+            const int iq = (i0 + u) & 3;
+            const unsigned slot = (wbase_half ^ (unsigned)((h << 6) ^ ((iq & 1) << 8))) + iq * 8192;
+            *reinterpret_cast<u32x4*>(lds + slot) = as_u32x4(f32x8_to_bf16(v));
+            *reinterpret_cast<u32x4*>(lds + 65536 + slot) = as_u32x4(f32x8_to_bf16(sv));
           }
         }
       }
