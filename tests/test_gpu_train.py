@@ -38,6 +38,26 @@ def rel_err(a, b):
     return ((a - b).norm() / (b.norm() + 1e-12)).item()
 
 
+def assert_accumulates_twice(m, g1, g2):
+    """Two backward passes over one batch leave twice the gradient of one -- for the whole flat buffer and for EVERY parameter on its
+    own (a tensor that was overwritten instead of accumulated, or skipped, reads 0.5 here however small it is).  The bounds are not
+    rounding-tight on purpose, measured with tools/probes/linearity_by_param.py on the bench workload: fp32 atomics make the head's
+    token gradient differ in the last bit between passes, every bf16 rounding of the gradient stream amplifies that until it sits at
+    the bf16 noise floor (2e-3 of the norm between any two passes), and the batch-hard triplet loss picks arg max / arg min pairs
+    among near-tied distances of a synthetic batch, so a pick can flip between passes: a discrete 9e-3 change of the trunk gradient
+    (up to 2e-2 of a single tensor), gone with the triplet weight at 0."""
+    rel = ((g2 - 2 * g1).norm() / (2 * g1).norm()).item()
+    assert rel < 1e-2, rel
+    worst = (0.0, None)
+    for name, (o, shape, n) in m.ptab.index.items():
+        a, b = g1[o:o + n], g2[o:o + n]
+        if a.norm().item() > 0:
+            r = ((b - 2 * a).norm() / (2 * a).norm()).item()
+            if r > worst[0]:
+                worst = (r, name)
+    assert worst[0] < 0.1, worst
+
+
 @pytest.mark.parametrize("arch,direct,head", [("clip", 1, 4), ("vit", 1, 2), ("clip", 0, 4)])
 def test_small_train_step_fp32(arch, direct, head):
     cfg = small_cfg(arch, head=head, direct=direct)
@@ -266,8 +286,7 @@ def test_bench_size_gradient_accumulation_is_linear_bf16_other_configs(which):
     torch.cuda.synchronize()
     m.check_errors()
     assert abs(l1 - l2) < 1e-3 * abs(l1) and torch.isfinite(g1).all() and g1.abs().max() > 0
-    rel = ((g2 - 2 * g1).norm() / (2 * g1).norm()).item()
-    assert rel < 2e-3, rel
+    assert_accumulates_twice(m, g1, g2)
     assert int(m._nbt_flat[0]) == 2
     # every expert of every head and every per-modality head received a gradient
     for n, p in m.named_parameters():
@@ -303,8 +322,8 @@ def test_graph_replay_matches_eager_steps():
 
 def test_bench_size_gradient_accumulation_is_linear_bf16():
     """B = 128, config A, bf16 (the bench workload): gradients ACCUMULATE into the flat buffer, so two backward passes over the
-    same batch must give twice the gradient of one (dropout off; everything else in the step is deterministic up to the
-    summation order of atomics), and the loss must not depend on how often it was evaluated."""
+    same batch must give twice the gradient of one (dropout off), in total and per parameter (`assert_accumulates_twice` says what
+    the bounds allow for), and the loss must not depend on how often it was evaluated."""
     cfg = make_cfg("RGBNT201")
     m, _ = build(cfg, 171, 4, torch.bfloat16)
     x, cam = synth_batch(128, 256, 128, 4, seed=21)
@@ -318,8 +337,7 @@ def test_bench_size_gradient_accumulation_is_linear_bf16():
     g2 = m.grad_buffer().clone()
     torch.cuda.synchronize()
     assert abs(l1 - l2) < 1e-3 * abs(l1) and torch.isfinite(g1).all()
-    rel = ((g2 - 2 * g1).norm() / (2 * g1).norm()).item()
-    assert rel < 2e-3, rel
+    assert_accumulates_twice(m, g1, g2)
     assert int(m._nbt_flat[0]) == 2                                  # every BatchNorm saw two batches
 
 
