@@ -35,6 +35,7 @@ step attention;            python tools/bench_attn.py > $O/bench_attn.txt 2>&1 |
 step layernorm;            python tools/bench_ln.py > $O/bench_ln.txt 2>&1 || echo FAILED
 [ -x tools/probes/store_probe ] || hipcc --offload-arch=gfx950 -O3 tools/probes/store_probe.hip -o tools/probes/store_probe
 step store probe;          tools/probes/store_probe > $O/store_probe.txt 2>&1 || echo FAILED
+step linearity;            { python tools/probes/linearity_by_param.py 8; echo "== triplet weight 0"; LIN_TRIPLET=0 python tools/probes/linearity_by_param.py 8; } 2>&1 | grep -v "amdgpu.ids\|Building DeMo" > $O/linearity_by_param.txt || echo FAILED
 step eval latency;         bash tools/eval_latency.sh > $O/eval_latency.txt 2>&1 || echo FAILED
 step eval kernel stats;    bash tools/eval_profile.sh > $O/eval_profile.log 2>&1 || echo FAILED
 for f in b1_f1 b1_f0 b64_f1; do cp gpurun_out/lat/prof_$f/p_kernel_stats.csv $O/fwd_${f}_kernel_stats.csv 2>/dev/null; done
