@@ -187,15 +187,16 @@ __device__ __forceinline__ v2f act_both2(v2f x, int act, v2f& d) {
 }
 
 // ---- DEMO_D8: 8-bit code of a saved activation derivative (demo_hip.h) ----------------------------------------------------------
-// q = rint((a + 0.13) * 200): the rounding is done explicitly (v_rndne_f32), so the byte conversion sees an integer and its own
-// rounding mode does not matter; v_cvt_pk_u8_f32 saturates to [0, 255] and inserts the byte into a dword.
+// q = rint((a + 0.13) * 200): v_cvt_pk_u8_f32 rounds to nearest even by itself (under the kernels' default fp32 rounding mode), saturates to
+// [0, 255] and inserts the byte into a dword -- tools/probes/cvt_u8_probe.hip compares it with an explicit v_rndne_f32 in front (ties, both
+// ends of the range, negatives: identical), so the encoder is one fma (two-wide) and one conversion per element.
 __device__ __forceinline__ uint32_t d8_pack4(v2f a, v2f b) {
   const v2f qa = pk_fma(a, 200.0f, 26.0f), qb = pk_fma(b, 200.0f, 26.0f);
   uint32_t w = 0;
-  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(qa.x), 0, w);
-  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(qa.y), 1, w);
-  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(qb.x), 2, w);
-  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(qb.y), 3, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(qa.x, 0, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(qa.y, 1, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(qb.x, 2, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(qb.y, 3, w);
   return w;
 }
 __device__ __forceinline__ uint32_t d8_pack4(float a0, float a1, float a2, float a3) { return d8_pack4((v2f){a0, a1}, (v2f){a2, a3}); }
