@@ -29,7 +29,7 @@ step fwd B=1;              python bench.py --mode fwd --batch 1 --steps 200 --wa
 step gemm cost;            python tools/gemm_cost.py > $O/gemm_cost.txt 2>&1 || echo FAILED
 step vendor blas;          python tools/bench_blas_ref.py > $O/vendor_blas_reference.txt 2>&1 || echo FAILED
 step cu fill;              python tools/bench_cu_fill.py > $O/cu_fill.txt 2>&1 || echo FAILED
-step d8 accuracy;          python tools/probes/act_deriv_d8_accuracy.py > $O/act_deriv_d8_accuracy.txt 2>&1 || echo FAILED
+step d8 accuracy;          { python tools/probes/act_deriv_d8_accuracy.py; python tools/probes/act_deriv_d8_accuracy.py --no-triplet; } > $O/act_deriv_d8_accuracy.txt 2>&1 || echo FAILED
 step tn;                   python tools/bench_gemm_tn.py > $O/bench_gemm_tn.txt 2>&1 || echo FAILED
 step attention;            python tools/bench_attn.py > $O/bench_attn.txt 2>&1 || echo FAILED
 step layernorm;            python tools/bench_ln.py > $O/bench_ln.txt 2>&1 || echo FAILED
