@@ -54,12 +54,7 @@ __global__ __launch_bounds__(256, NT <= 9 ? 2 : 1) void attn_bwd_bf16_kernel(con
                                                                              const float* __restrict__ lse,
                                                                              bf16_t* __restrict__ dqkv, int L, int H, float scale) {
   constexpr int LP = NT * 16, MAT_BYTES = LP * 128, NIT = (LP * 8 + 255) / 256;
-  // -DDEMO_ATTN_BWD_PAD=bytes (measurement builds only): unused LDS that pushes the kernel from two workgroups per CU to one -- how much of
-  // its time is the overlap of one workgroup's load phase with another's compute phase
-#ifndef DEMO_ATTN_BWD_PAD
-#define DEMO_ATTN_BWD_PAD 0
-#endif
-  __shared__ __attribute__((aligned(1024))) char smem[4 * MAT_BYTES + 2 * LP * 4 + DEMO_ATTN_BWD_PAD];
+  __shared__ __attribute__((aligned(1024))) char smem[4 * MAT_BYTES + 2 * LP * 4];
   char* Qs = smem;
   char* Gs = smem + MAT_BYTES;                // dO
   char* Ks = smem + 2 * MAT_BYTES;
